@@ -1,0 +1,102 @@
+// Host build of the device arithmetic headers (test infrastructure): the same
+// __host__ __device__ code that the gfx950 kernels inline is compiled with g++ and
+// exposed over a C ABI so the CPU test-suite can check it against the oracle.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#include "../../plonk_amd/csrc/g1.cuh"
+#include "../../plonk_amd/csrc/msm_core.cuh"
+
+using namespace plonk;
+
+template <class C>
+static Fe<C> ld(const uint32_t *p) {
+    Fe<C> r;
+    memcpy(r.l, p, sizeof(r.l));
+    return r;
+}
+template <class C>
+static void st(uint32_t *p, const Fe<C> &v) {
+    memcpy(p, v.l, sizeof(v.l));
+}
+
+#define VEC2(name, C, fn)                                                               \
+    extern "C" void name(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n) { \
+        for (size_t i = 0; i < n; i++)                                                  \
+            st<C>(out + C::N * i, fn(ld<C>(a + C::N * i), ld<C>(b + C::N * i)));       \
+    }
+#define VEC1(name, C, fn)                                                \
+    extern "C" void name(const uint32_t *a, uint32_t *out, size_t n) {   \
+        for (size_t i = 0; i < n; i++) st<C>(out + C::N * i, fn(ld<C>(a + C::N * i))); \
+    }
+
+VEC2(hc_fq_mul, FqCfg, fe_mul<FqCfg>)
+VEC2(hc_fq_add, FqCfg, fe_add<FqCfg>)
+VEC2(hc_fq_sub, FqCfg, fe_sub<FqCfg>)
+VEC1(hc_fq_inv, FqCfg, fe_inv<FqCfg>)
+VEC1(hc_fq_dbl, FqCfg, fe_dbl<FqCfg>)
+VEC1(hc_fq_neg, FqCfg, fe_neg<FqCfg>)
+VEC1(hc_fq_from_mont, FqCfg, fe_from_mont<FqCfg>)
+VEC1(hc_fq_to_mont, FqCfg, fe_to_mont<FqCfg>)
+VEC2(hc_fr_mul, FrCfg, fe_mul<FrCfg>)
+VEC2(hc_fr_add, FrCfg, fe_add<FrCfg>)
+VEC2(hc_fr_sub, FrCfg, fe_sub<FrCfg>)
+VEC1(hc_fr_inv, FrCfg, fe_inv<FrCfg>)
+VEC1(hc_fr_dbl, FrCfg, fe_dbl<FrCfg>)
+VEC1(hc_fr_from_mont, FrCfg, fe_from_mont<FrCfg>)
+VEC1(hc_fr_to_mont, FrCfg, fe_to_mont<FrCfg>)
+
+static G1Xyzz ldx(const uint32_t *p) {
+    G1Xyzz r;
+    memcpy(&r, p, sizeof(r));
+    return r;
+}
+static G1Affine lda(const uint32_t *p) {
+    G1Affine r;
+    memcpy(&r, p, sizeof(r));
+    return r;
+}
+static G1Jac ldj(const uint32_t *p) {
+    G1Jac r;
+    memcpy(&r, p, sizeof(r));
+    return r;
+}
+
+extern "C" void hc_xyzz_madd(const uint32_t *acc, const uint32_t *aff, int negate, uint32_t *out) {
+    G1Xyzz a = ldx(acc);
+    xyzz_madd(a, lda(aff), negate != 0);
+    memcpy(out, &a, sizeof(a));
+}
+extern "C" void hc_xyzz_add(const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    G1Xyzz r = xyzz_add(ldx(a), ldx(b));
+    memcpy(out, &r, sizeof(r));
+}
+extern "C" void hc_xyzz_dbl(const uint32_t *a, uint32_t *out) {
+    G1Xyzz r = xyzz_dbl(ldx(a));
+    memcpy(out, &r, sizeof(r));
+}
+extern "C" void hc_xyzz_to_jac(const uint32_t *a, uint32_t *out) {
+    G1Jac r = xyzz_to_jac(ldx(a));
+    memcpy(out, &r, sizeof(r));
+}
+extern "C" void hc_jac_to_xyzz(const uint32_t *a, uint32_t *out) {
+    G1Xyzz r = jac_to_xyzz(ldj(a));
+    memcpy(out, &r, sizeof(r));
+}
+extern "C" void hc_jac_dbl(const uint32_t *a, uint32_t *out) {
+    G1Jac r = jac_dbl(ldj(a));
+    memcpy(out, &r, sizeof(r));
+}
+extern "C" void hc_xyzz_from_affine(const uint32_t *a, uint32_t *out) {
+    G1Xyzz r = xyzz_from_affine(lda(a));
+    memcpy(out, &r, sizeof(r));
+}
+
+// Signed window digits of a Montgomery-form scalar (see msm_core.cuh).
+extern "C" void hc_scalar_digits(const uint32_t *scalar_mont, int c, int nwin, int32_t *out) {
+    Fr k = fe_from_mont(ld<FrCfg>(scalar_mont));
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; w++) out[w] = signed_digit(k, w, c, carry);
+}
+extern "C" int hc_num_windows(int c) { return msm_num_windows(c); }

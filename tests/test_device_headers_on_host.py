@@ -1,0 +1,145 @@
+"""The gfx950 kernels inline plonk_amd/csrc/{field,g1,msm_core}.cuh.  Those headers are
+__host__ __device__; here the host build is checked against the oracle so that arithmetic
+errors are caught without a GPU."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from oracle import capi as c
+from oracle import pyref as o
+from tests.hostcheck import build as hc_build
+
+u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    c.build()
+    return hc_build.load()
+
+
+def _p32(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def _vec2(fn, a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    out = np.empty_like(a)
+    fn(_p32(a), _p32(b), _p32(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def _vec1(fn, a):
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    fn(_p32(a), _p32(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_field_ops(hc, field):
+    rnd = random.Random(21)
+    mod = o.Q if field == "fq" else o.R
+    to_m = c.fq_to_mont if field == "fq" else c.fr_to_mont
+    from_m = c.fq_from_mont if field == "fq" else c.fr_from_mont
+    a = [rnd.randrange(mod) for _ in range(200)] + [0, 1, mod - 1, mod - 1, 0, 2]
+    b = [rnd.randrange(mod) for _ in range(200)] + [mod - 1, 0, mod - 1, 1, 0, mod - 2]
+    A, B = to_m(a), to_m(b)
+    f = lambda name: getattr(hc, "hc_%s_%s" % (field, name))
+    assert from_m(_vec2(f("mul"), A, B)) == [x * y % mod for x, y in zip(a, b)]
+    assert from_m(_vec2(f("add"), A, B)) == [(x + y) % mod for x, y in zip(a, b)]
+    assert from_m(_vec2(f("sub"), A, B)) == [(x - y) % mod for x, y in zip(a, b)]
+    assert from_m(_vec1(f("dbl"), A)) == [2 * x % mod for x in a]
+    # Montgomery conversions: canonical limbs in, Montgomery limbs out and back
+    canon = c.ints_to_limbs(a, 6 if field == "fq" else 4)
+    assert np.array_equal(_vec1(f("to_mont"), canon), A)
+    assert np.array_equal(_vec1(f("from_mont"), A), canon)
+    inv = from_m(_vec1(f("inv"), A[:12]))
+    assert inv == [pow(x, -1, mod) for x in a[:12]]
+    assert from_m(_vec1(f("inv"), to_m([0])))[0] == 0
+
+
+def _xyzz_to_point(hc, x):
+    """XYZZ limbs (48 u32 as 24 u64) -> pyref Jacobian triple via the header's own converter."""
+    out = np.empty(18, dtype=np.uint64)
+    hc.hc_xyzz_to_jac(_p32(np.ascontiguousarray(x)), _p32(out))
+    return c.g1_from_limbs(out)[0]
+
+
+def test_group_law(hc):
+    rnd = random.Random(22)
+    g = c.g1_generator()
+    pts = [c.g1_mul(g, c.fr_to_mont([rnd.randrange(1, o.R)])[0]) for _ in range(6)]
+    aff = c.g1_to_affine(np.stack(pts))
+    ref = c.g1_from_limbs(np.stack(pts))
+    ident = np.zeros(24, dtype=np.uint64)
+    assert o.g1_is_identity(_xyzz_to_point(hc, ident))
+
+    def madd(acc, a, neg):
+        out = np.empty(24, dtype=np.uint64)
+        hc.hc_xyzz_madd(_p32(np.ascontiguousarray(acc)), _p32(np.ascontiguousarray(a)), int(neg), _p32(out))
+        return out
+
+    def add(a, b):
+        out = np.empty(24, dtype=np.uint64)
+        hc.hc_xyzz_add(_p32(np.ascontiguousarray(a)), _p32(np.ascontiguousarray(b)), _p32(out))
+        return out
+
+    def dbl(a):
+        out = np.empty(24, dtype=np.uint64)
+        hc.hc_xyzz_dbl(_p32(np.ascontiguousarray(a)), _p32(out))
+        return out
+
+    # identity + P, then generic adds, P + P, P - P, identity operand
+    acc = madd(ident, aff[0], False)
+    assert o.g1_eq(_xyzz_to_point(hc, acc), ref[0])
+    acc = madd(acc, aff[1], False)
+    want = o.g1_add(ref[0], ref[1])
+    assert o.g1_eq(_xyzz_to_point(hc, acc), want)
+    acc = madd(acc, aff[2], True)
+    want = o.g1_sub(want, ref[2])
+    assert o.g1_eq(_xyzz_to_point(hc, acc), want)
+    assert o.g1_eq(_xyzz_to_point(hc, madd(acc, np.zeros(12, dtype=np.uint64), False)), want)
+    one = madd(ident, aff[3], False)
+    assert o.g1_eq(_xyzz_to_point(hc, madd(one, aff[3], False)), o.g1_double(ref[3]))
+    assert o.g1_is_identity(_xyzz_to_point(hc, madd(one, aff[3], True)))
+    # doubling of a non-trivial XYZZ value, then P + P through the full add
+    assert o.g1_eq(_xyzz_to_point(hc, dbl(acc)), o.g1_double(want))
+    assert o.g1_eq(_xyzz_to_point(hc, add(acc, acc)), o.g1_double(want))
+    other = madd(madd(ident, aff[4], False), aff[5], False)
+    w2 = o.g1_add(ref[4], ref[5])
+    assert o.g1_eq(_xyzz_to_point(hc, add(acc, other)), o.g1_add(want, w2))
+    assert o.g1_eq(_xyzz_to_point(hc, add(acc, ident)), want)
+    assert o.g1_eq(_xyzz_to_point(hc, add(ident, other)), w2)
+    # a + (-a): negate through a Jacobian round trip
+    neg = c.g1_to_limbs([o.g1_neg(want)])[0]
+    nx = np.empty(24, dtype=np.uint64)
+    hc.hc_jac_to_xyzz(_p32(np.ascontiguousarray(neg)), _p32(nx))
+    assert o.g1_is_identity(_xyzz_to_point(hc, add(acc, nx)))
+    # Jacobian doubling used by the SRS window tables
+    jd = np.empty(18, dtype=np.uint64)
+    hc.hc_jac_dbl(_p32(np.ascontiguousarray(pts[0])), _p32(jd))
+    assert o.g1_eq(c.g1_from_limbs(jd)[0], o.g1_double(ref[0]))
+    hc.hc_jac_dbl(_p32(np.ascontiguousarray(c.g1_identity())), _p32(jd))
+    assert o.g1_is_identity(c.g1_from_limbs(jd)[0])
+
+
+@pytest.mark.parametrize("cbits", [2, 3, 7, 8, 13, 15, 16, 17, 20, 24])
+def test_signed_digits_recompose(hc, cbits):
+    rnd = random.Random(23 + cbits)
+    nwin = hc.hc_num_windows(cbits)
+    assert nwin == 255 // cbits + 1
+    vals = [0, 1, o.R - 1, o.R - 2, (1 << 255) % o.R, (1 << 254) - 1] + [rnd.randrange(o.R) for _ in range(50)]
+    half = 1 << (cbits - 1)
+    # worst case for carries: every window at its maximum
+    vals.append(min(o.R - 1, (1 << 255) - 1))
+    for v in vals:
+        sm = np.ascontiguousarray(c.fr_to_mont([v])[0])
+        out = np.zeros(nwin, dtype=np.int32)
+        hc.hc_scalar_digits(_p32(sm), cbits, nwin, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        assert all(-half < int(d) <= half for d in out)
+        assert sum(int(d) << (cbits * w) for w, d in enumerate(out)) == v
