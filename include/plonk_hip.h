@@ -1,0 +1,170 @@
+/*
+ * libplonk_hip -- MI355X (gfx950) backend for the KZG / polynomial hot path of the
+ * hjeljeli32/plonk prover.  Flat C ABI: plain pointers and sizes, no C++ or framework types.
+ *
+ * This is the seam a Rust shim (`cc`/`build.rs`) binds: each entry point names the reference
+ * function it stands behind (paths relative to the reference repository root).
+ *
+ * Data formats (exactly ark-ff / ark-ec 0.5 in-memory layouts, little-endian u64 limbs,
+ * Montgomery form):
+ *   Fr            4 x u64   (R = 2^256)       -- `ark_bls12_381::Fr`
+ *   Fq            6 x u64   (R = 2^384)
+ *   G1 projective 18 x u64  X | Y | Z, Jacobian, identity <=> Z == 0 -- `G1Projective`
+ *   G1 affine     12 x u64  x | y, identity encoded as all-zero
+ * so `coeffs.as_ptr() as *const u64` and `tau_powers_g1.as_ptr() as *const u64` can be passed
+ * straight through.  Returned G1 values are valid Jacobian representatives (not normalised to
+ * Z = 1); ark's `==` and `serialize_compressed` are representation independent.
+ *
+ * Unless a name ends in `_dev`, pointers are HOST pointers, calls are synchronous and results
+ * are valid on return.  `_dev` entry points take DEVICE pointers (memory of the context's GPU),
+ * enqueue on the context's stream and return without waiting; call plonk_hip_sync().
+ * A context is bound to one GPU; calls on one context must not overlap (serialise them or use
+ * one context per thread).  All entry points return 0 on success or a negative PLONK_HIP_ERR_*.
+ * Nothing unwinds across this boundary.
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plonk_hip_ctx plonk_hip_ctx;
+
+enum {
+    PLONK_HIP_OK = 0,
+    /* kzg_commit: SRS shorter than the polynomial -> CommitError::CommitFailed
+     * (plonk/src/common/kzg.rs:11-15,49-50); in kzg_open the reference panics on the
+     * out-of-bounds index (kzg.rs:83) */
+    PLONK_HIP_ERR_SRS_TOO_SHORT = -1,
+    /* empty coefficient vector / quotient: the reference panics on `.reduce(..).unwrap()`
+     * (kzg.rs:57-58, :85) */
+    PLONK_HIP_ERR_EMPTY_POLY = -2,
+    /* inverse of zero: the reference panics on `.inverse().unwrap()`
+     * (plonk/src/common/polynomials.rs:42, plonk/src/common/protocols.rs:349,583) */
+    PLONK_HIP_ERR_ZERO_DENOMINATOR = -3,
+    PLONK_HIP_ERR_INVALID_ARG = -4,
+    PLONK_HIP_ERR_NO_SRS = -5,
+    PLONK_HIP_ERR_HIP = -6,         /* a HIP runtime call failed; see plonk_hip_last_error() */
+    PLONK_HIP_ERR_OUT_OF_MEMORY = -7,
+    PLONK_HIP_ERR_NOT_DIVISIBLE = -8 /* coset quotient asked for a polynomial Z_Omega does not divide */
+};
+
+/* ----------------------------------------------------------------------------------------
+ * Context
+ * -------------------------------------------------------------------------------------- */
+int plonk_hip_ctx_create(int device, plonk_hip_ctx **out);
+void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx);
+const char *plonk_hip_strerror(int code);
+/* Text of the last failing HIP call on this context ("" if none). */
+const char *plonk_hip_last_error(plonk_hip_ctx *ctx);
+/* Window width c of the signed-digit bucket method used for the NEXT SRS load (0 = choose
+ * from the SRS size).  2 <= c <= 24. */
+int plonk_hip_ctx_set_window_bits(plonk_hip_ctx *ctx, int c);
+/* The context's HIP stream (a hipStream_t), for callers that order their own work on it. */
+void *plonk_hip_ctx_stream(plonk_hip_ctx *ctx);
+int plonk_hip_sync(plonk_hip_ctx *ctx);
+
+/* Device memory of the context's GPU, for callers that keep data resident (`_dev` calls). */
+int plonk_hip_malloc(plonk_hip_ctx *ctx, size_t bytes, void **dptr);
+int plonk_hip_free(plonk_hip_ctx *ctx, void *dptr);
+int plonk_hip_memcpy_h2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ----------------------------------------------------------------------------------------
+ * SRS -- `GlobalParameters.tau_powers_g1` (plonk/src/common/kzg.rs:17-21)
+ * -------------------------------------------------------------------------------------- */
+/* Uploads n Jacobian points, normalises them to affine on the GPU and builds the resident
+ * window tables ([2^(c*w)]P_i for every window w).  Replaces any previous SRS. */
+int plonk_hip_srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts /* n x 18 */, size_t n);
+int plonk_hip_srs_size(plonk_hip_ctx *ctx, size_t *n);
+/* Reads back SRS points [first, first+count) as Jacobian triples with Z = 1. */
+int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out /* count x 18 */);
+
+/* `kzg_setup(degree)` (kzg.rs:24-45) with tau supplied by the caller: computes [tau^i]G for
+ * i = 0..degree on the GPU, installs the result as the context's SRS and, if out_pts is not
+ * NULL, returns it ((degree+1) x 18).  The reference's own tau is `Fr::rand(test_rng())`;
+ * drawing it stays on the caller's side.  tau_g2 (kzg.rs:39) is not produced here. */
+int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
+
+/* ----------------------------------------------------------------------------------------
+ * Commit / open -- the G1 MSM
+ * -------------------------------------------------------------------------------------- */
+/* `kzg_commit(gp, f)` (kzg.rs:48-60): out = sum_i coeffs[i] * tau_powers_g1[i], n = coeffs.len().
+ * n > SRS size -> PLONK_HIP_ERR_SRS_TOO_SHORT; n == 0 -> PLONK_HIP_ERR_EMPTY_POLY. */
+int plonk_hip_kzg_commit(plonk_hip_ctx *ctx, const uint64_t *coeffs /* n x 4 */, size_t n, uint64_t out[18]);
+/* Same with coefficients and result (18 x u64) in device memory; asynchronous. */
+int plonk_hip_kzg_commit_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_out);
+/* The batched commitments of the prover (protocols.rs:191-195, 287-288, 652-653, 761;
+ * prover/part1.rs:66, part2.rs:48; setup_verification_key/mod.rs:74,108): `batch`
+ * polynomials against the same SRS.  outs = batch x 18. */
+int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
+                               uint64_t *outs);
+
+/* `kzg_evaluate(gp, f, u)` (kzg.rs:63-88): v = f(u); q = (f - v) / (X - u);
+ * proof = sum_i q_i * tau_powers_g1[i].  n = coeffs.len().
+ * n < 2 -> PLONK_HIP_ERR_EMPTY_POLY (empty quotient); n - 1 > SRS size -> SRS_TOO_SHORT. */
+int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs /* n x 4 */, size_t n, const uint64_t u[4],
+                       uint64_t v[4], uint64_t proof[18]);
+/* Several openings of one polynomial (protocols.rs:655-659, 763-767: t at w^(k-1), rp, w*rp;
+ * T at r, w*r, w^2*r).  us = m x 4, vs = m x 4, proofs = m x 18. */
+int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
+                            uint64_t *vs, uint64_t *proofs);
+
+/* Per-phase GPU time (ms, HIP events on the context's stream) of the most recent MSM run by
+ * this context; valid after plonk_hip_profile(ctx, 1).  Phase names from
+ * plonk_hip_msm_phase_name(i), i < PLONK_HIP_MSM_PHASES. */
+#define PLONK_HIP_MSM_PHASES 6
+int plonk_hip_profile(plonk_hip_ctx *ctx, int enable);
+int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]);
+const char *plonk_hip_msm_phase_name(int i);
+/* Window plan in force: bits per window, windows, buckets. */
+int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
+
+/* ----------------------------------------------------------------------------------------
+ * Polynomials over Fr
+ * -------------------------------------------------------------------------------------- */
+/* Evaluations over Omega = construct_Omega(2^log_n) (plonk/src/common/utils.rs:11-38,
+ * omega = 7^((r-1)/n)), natural order in and out, in place, `batch` vectors of 2^log_n
+ * elements stored back to back.
+ *   inverse = 0: data[j] <- f(omega^j), the evaluations the reference takes one Horner at a
+ *                time (protocols.rs:243-250, 345-353, 461-468, 571-588; prover/part4.rs:36-42);
+ *   inverse = 1: data <- coefficients of `interpolate_polynomial(Omega, data)`
+ *                (plonk/src/common/polynomials.rs:50-58), zero padded to 2^log_n. */
+int plonk_hip_fr_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, int inverse);
+int plonk_hip_fr_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch, int inverse);
+/* The same over the coset shift * Omega: forward evaluates f at shift*omega^j, inverse
+ * interpolates from those values. */
+int plonk_hip_fr_coset_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, const uint64_t shift[4],
+                           int inverse);
+int plonk_hip_fr_coset_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch,
+                               const uint64_t shift[4], int inverse);
+
+/* `compose_polynomials(f, [0, w])` = f(wX): coeffs[i] <- coeffs[i] * w^i
+ * (polynomials.rs:80-113 as called from protocols.rs:258-270, 361-380, 596-633, 728-740;
+ * prover/part3.rs:42-54). */
+int plonk_hip_fr_scale_by_powers(plonk_hip_ctx *ctx, uint64_t *coeffs, size_t n, const uint64_t w[4]);
+
+/* `f.evaluate(&u)` (kzg.rs:65). */
+int plonk_hip_fr_eval(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t out[4]);
+
+/* `compute_q_zero_test(k, f)` (protocols.rs:157-166): quotient of f (n coefficients) by
+ * X^k - 1 with the remainder dropped, exactly as long division gives it, whether or not
+ * X^k - 1 divides f.  q receives n - k coefficients (n > k), untrimmed. */
+int plonk_hip_fr_div_vanishing(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, size_t k, uint64_t *q);
+/* The same quotient for `batch` polynomials of n = 2^(log_k+1) coefficients each, k = 2^log_k,
+ * by coset evaluation: coset-NTT on the 2k domain, pointwise division by Z on the coset,
+ * coset-iNTT.  Equal to long division only when X^k - 1 divides f; divisible[b] reports
+ * whether it did (the top k coefficients of the result vanished).  q = batch x k x 4. */
+int plonk_hip_fr_quotient_coset(plonk_hip_ctx *ctx, const uint64_t *f, uint32_t log_k, size_t batch, uint64_t *q,
+                                int *divisible);
+int plonk_hip_fr_quotient_coset_dev(plonk_hip_ctx *ctx, void *d_f_inout, uint32_t log_k, size_t batch,
+                                    int *d_divisible);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

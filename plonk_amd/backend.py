@@ -1,0 +1,248 @@
+"""Python view of one library context.
+
+Mirrors the reference's `common::kzg` / `common::polynomials` surface on limb arrays:
+numpy uint64, little-endian limbs, Montgomery form (Fr = 4 limbs, G1 projective = 18)."""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+
+ERR_SRS_TOO_SHORT = -1
+ERR_EMPTY_POLY = -2
+ERR_ZERO_DENOMINATOR = -3
+
+
+class PlonkHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("plonk_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class CommitError(PlonkHipError):
+    """`CommitError::CommitFailed` of the reference (plonk/src/common/kzg.rs:11-15)."""
+
+
+class ReferencePanic(PlonkHipError):
+    """Inputs on which the reference panics (empty reduce, out-of-bounds index, inverse of 0)."""
+
+
+def _u64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_l.c_u64p)
+
+
+def _fr(a, cols=4):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, cols)
+
+
+class Backend:
+    def __init__(self, device=0, window_bits=0):
+        self._lib = _l.load_library()
+        self._ctx = _l.c_ctx()
+        rc = self._lib.plonk_hip_ctx_create(device, ctypes.byref(self._ctx))
+        if rc != 0:
+            raise PlonkHipError(rc, self._lib.plonk_hip_strerror(rc).decode())
+        self.device = device
+        if window_bits:
+            self._check(self._lib.plonk_hip_ctx_set_window_bits(self._ctx, window_bits))
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if self._ctx:
+            self._lib.plonk_hip_ctx_destroy(self._ctx)
+            self._ctx = _l.c_ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        text = self._lib.plonk_hip_strerror(rc).decode()
+        detail = self._lib.plonk_hip_last_error(self._ctx).decode()
+        if detail and rc in (-6, -7):
+            text += " (" + detail + ")"
+        if rc == ERR_SRS_TOO_SHORT:
+            raise CommitError(rc, text)
+        if rc in (ERR_EMPTY_POLY, ERR_ZERO_DENOMINATOR):
+            raise ReferencePanic(rc, text)
+        raise PlonkHipError(rc, text)
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    @property
+    def stream(self):
+        return self._lib.plonk_hip_ctx_stream(self._ctx)
+
+    def sync(self):
+        self._check(self._lib.plonk_hip_sync(self._ctx))
+
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self._lib.plonk_hip_malloc(self._ctx, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self._check(self._lib.plonk_hip_free(self._ctx, dptr))
+
+    def to_device(self, arr, dptr=None):
+        arr = np.ascontiguousarray(arr)
+        if dptr is None:
+            dptr = self.malloc(arr.nbytes)
+        self._check(self._lib.plonk_hip_memcpy_h2d(self._ctx, dptr, arr.ctypes.data, arr.nbytes))
+        return dptr
+
+    def from_device(self, dptr, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.plonk_hip_memcpy_d2h(self._ctx, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def set_window_bits(self, c):
+        self._check(self._lib.plonk_hip_ctx_set_window_bits(self._ctx, c))
+
+    def profile(self, enable=True):
+        self._check(self._lib.plonk_hip_profile(self._ctx, 1 if enable else 0))
+
+    def msm_phase_ms(self):
+        ms = (ctypes.c_float * 6)()
+        self._check(self._lib.plonk_hip_msm_phase_ms(self._ctx, ms))
+        return {self._lib.plonk_hip_msm_phase_name(i).decode(): float(ms[i]) for i in range(6)}
+
+    def msm_plan(self):
+        c, w, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        self._check(self._lib.plonk_hip_msm_plan(self._ctx, ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)))
+        return {"window_bits": c.value, "windows": w.value, "buckets": b.value}
+
+    # ------------------------------------------------------------------ SRS
+    def srs_load_projective(self, pts):
+        """`GlobalParameters.tau_powers_g1` (kzg.rs:17-21): (n, 18) Jacobian limbs."""
+        pts = _fr(pts, 18)
+        self._check(self._lib.plonk_hip_srs_load_projective(self._ctx, _u64(pts), pts.shape[0]))
+
+    def srs_size(self):
+        n = ctypes.c_size_t()
+        self._check(self._lib.plonk_hip_srs_size(self._ctx, ctypes.byref(n)))
+        return n.value
+
+    def srs_read(self, first, count):
+        out = np.empty((count, 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_srs_read(self._ctx, first, count, _u64(out)))
+        return out
+
+    def kzg_setup(self, tau, degree, want_points=True):
+        """`kzg_setup(degree)` (kzg.rs:24-45) for a caller-supplied tau."""
+        tau = _fr(tau).reshape(4)
+        out = np.empty((degree + 1, 18), dtype=np.uint64) if want_points else None
+        self._check(self._lib.plonk_hip_kzg_setup(self._ctx, _u64(tau), degree, _u64(out) if want_points else None))
+        return out
+
+    # ------------------------------------------------------------------ commit / open
+    def kzg_commit(self, coeffs):
+        """`kzg_commit(gp, f)` (kzg.rs:48-60) -> (18,) Jacobian limbs."""
+        coeffs = _fr(coeffs)
+        out = np.empty(18, dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_commit(self._ctx, _u64(coeffs), coeffs.shape[0], _u64(out)))
+        return out
+
+    def kzg_commit_dev(self, d_coeffs, n, d_out):
+        self._check(self._lib.plonk_hip_kzg_commit_dev(self._ctx, d_coeffs, n, d_out))
+
+    def kzg_commit_batch(self, polys):
+        polys = [_fr(p) for p in polys]
+        ptrs = (_l.c_u64p * len(polys))(*[_u64(p) for p in polys])
+        ns = (ctypes.c_size_t * len(polys))(*[p.shape[0] for p in polys])
+        outs = np.empty((len(polys), 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_commit_batch(self._ctx, ptrs, ns, len(polys), _u64(outs)))
+        return outs
+
+    def kzg_evaluate(self, coeffs, u):
+        """`kzg_evaluate(gp, f, u)` (kzg.rs:63-88) -> (v (4,), proof (18,))."""
+        coeffs = _fr(coeffs)
+        u = _fr(u).reshape(4)
+        v = np.empty(4, dtype=np.uint64)
+        proof = np.empty(18, dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_open(self._ctx, _u64(coeffs), coeffs.shape[0], _u64(u), _u64(v),
+                                                 _u64(proof)))
+        return v, proof
+
+    def kzg_evaluate_many(self, coeffs, us):
+        coeffs = _fr(coeffs)
+        us = _fr(us)
+        vs = np.empty((us.shape[0], 4), dtype=np.uint64)
+        proofs = np.empty((us.shape[0], 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_open_many(self._ctx, _u64(coeffs), coeffs.shape[0], _u64(us),
+                                                      us.shape[0], _u64(vs), _u64(proofs)))
+        return vs, proofs
+
+    # ------------------------------------------------------------------ polynomials
+    def fr_ntt(self, data, inverse=False, shift=None):
+        """Evaluations over Omega (forward) / interpolation over Omega (inverse); natural order.
+        data: (batch, 2^k, 4) or (2^k, 4).  Returns a new array."""
+        d = np.array(data, dtype=np.uint64)
+        shape = d.shape
+        d = d.reshape(-1, shape[-2], 4) if d.ndim == 3 else d.reshape(1, -1, 4)
+        n = d.shape[1]
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        if shift is None:
+            rc = self._lib.plonk_hip_fr_ntt(self._ctx, _u64(d), log_n, d.shape[0], 1 if inverse else 0)
+        else:
+            s = _fr(shift).reshape(4)
+            rc = self._lib.plonk_hip_fr_coset_ntt(self._ctx, _u64(d), log_n, d.shape[0], _u64(s), 1 if inverse else 0)
+        self._check(rc)
+        return d.reshape(shape)
+
+    def fr_ntt_dev(self, dptr, log_n, batch, inverse=False):
+        self._check(self._lib.plonk_hip_fr_ntt_dev(self._ctx, dptr, log_n, batch, 1 if inverse else 0))
+
+    def interpolate_over_omega(self, ys):
+        """`interpolate_polynomial(construct_Omega(n), ys)` (polynomials.rs:50-58)."""
+        return self.fr_ntt(ys, inverse=True)
+
+    def evaluate_over_omega(self, coeffs):
+        return self.fr_ntt(coeffs, inverse=False)
+
+    def compose_with_scaling(self, coeffs, w):
+        """`compose_polynomials(f, [0, w])` (polynomials.rs:80-113): f(wX)."""
+        c = np.array(_fr(coeffs))
+        w = _fr(w).reshape(4)
+        self._check(self._lib.plonk_hip_fr_scale_by_powers(self._ctx, _u64(c), c.shape[0], _u64(w)))
+        return c
+
+    def fr_eval(self, coeffs, u):
+        coeffs = _fr(coeffs)
+        u = _fr(u).reshape(4)
+        out = np.empty(4, dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_eval(self._ctx, _u64(coeffs), coeffs.shape[0], _u64(u), _u64(out)))
+        return out
+
+    def compute_q_zero_test(self, k, f):
+        """`compute_q_zero_test(k, f)` (protocols.rs:157-166): long-division quotient by X^k - 1."""
+        f = _fr(f)
+        n = f.shape[0]
+        q = np.zeros((max(n - k, 0), 4), dtype=np.uint64)
+        if n > k:
+            self._check(self._lib.plonk_hip_fr_div_vanishing(self._ctx, _u64(f), n, k, _u64(q)))
+        return q
+
+    def quotient_coset(self, f):
+        """Batch of polynomials with 2k coefficients each -> (q (batch, k, 4), divisible flags)."""
+        f = np.ascontiguousarray(f, dtype=np.uint64)
+        f = f.reshape(-1, f.shape[-2], 4) if f.ndim == 3 else f.reshape(1, -1, 4)
+        n = f.shape[1]
+        k = n // 2
+        log_k = k.bit_length() - 1
+        assert 2 << log_k == n
+        q = np.empty((f.shape[0], k, 4), dtype=np.uint64)
+        flags = (ctypes.c_int * f.shape[0])()
+        self._check(self._lib.plonk_hip_fr_quotient_coset(self._ctx, _u64(f), log_k, f.shape[0], _u64(q), flags))
+        return q, [bool(x) for x in flags]
+
+    def quotient_coset_dev(self, dptr, log_k, batch, d_flags=None):
+        self._check(self._lib.plonk_hip_fr_quotient_coset_dev(self._ctx, dptr, log_k, batch, d_flags))

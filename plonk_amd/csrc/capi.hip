@@ -1,0 +1,378 @@
+// C ABI of libplonk_hip (see include/plonk_hip.h for the contract of every entry point).
+#include <cstring>
+#include <new>
+
+#include "context.hpp"
+#include "poly.hpp"
+
+using namespace plonk;
+
+namespace plonk {
+
+int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return PLONK_HIP_OK;
+    if (b.ptr) {
+        // kernels already queued may still read the old allocation
+        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        PLONK_HIP_TRY(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    size_t rounded = (bytes + 255) & ~(size_t)255;
+    PLONK_HIP_TRY(ctx, hipMalloc(&b.ptr, rounded));
+    b.bytes = rounded;
+    return PLONK_HIP_OK;
+}
+
+void buf_release(DevBuf &b) {
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+}  // namespace plonk
+
+static int bind(plonk_hip_ctx *ctx) {
+    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return PLONK_HIP_OK;
+}
+
+static Fr load_fr(const uint64_t v[4]) {
+    Fr r;
+    memcpy(r.l, v, sizeof(r.l));
+    return r;
+}
+
+extern "C" {
+
+int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
+    if (!out) return PLONK_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PLONK_HIP_ERR_HIP;
+    plonk_hip_ctx *ctx = new (std::nothrow) plonk_hip_ctx();
+    if (!ctx) return PLONK_HIP_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return PLONK_HIP_ERR_HIP;
+    }
+    for (int i = 0; i <= PH_COUNT; i++) {
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
+            delete ctx;
+            return PLONK_HIP_ERR_HIP;
+        }
+    }
+    *out = ctx;
+    return PLONK_HIP_OK;
+}
+
+void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
+                      &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->red_a,
+                      &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
+                      &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table};
+    for (DevBuf *b : bufs) buf_release(*b);
+    for (int d = 0; d < 2; d++)
+        for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
+    for (int i = 0; i <= PH_COUNT; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *plonk_hip_strerror(int code) {
+    switch (code) {
+        case PLONK_HIP_OK: return "ok";
+        case PLONK_HIP_ERR_SRS_TOO_SHORT:
+            return "Length of tau_powers_g1 must be at least equal to degree of polynomial + 1";
+        case PLONK_HIP_ERR_EMPTY_POLY: return "empty coefficient vector (the reference panics on unwrap)";
+        case PLONK_HIP_ERR_ZERO_DENOMINATOR: return "inverse of zero";
+        case PLONK_HIP_ERR_INVALID_ARG: return "invalid argument";
+        case PLONK_HIP_ERR_NO_SRS: return "no SRS loaded in this context";
+        case PLONK_HIP_ERR_HIP: return "HIP runtime error";
+        case PLONK_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case PLONK_HIP_ERR_NOT_DIVISIBLE: return "polynomial is not divisible by the vanishing polynomial";
+        default: return "unknown error";
+    }
+}
+
+const char *plonk_hip_last_error(plonk_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int plonk_hip_ctx_set_window_bits(plonk_hip_ctx *ctx, int c) {
+    if (!ctx || (c != 0 && (c < 2 || c > 24))) return PLONK_HIP_ERR_INVALID_ARG;
+    ctx->window_bits_override = c;
+    return PLONK_HIP_OK;
+}
+
+void *plonk_hip_ctx_stream(plonk_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int plonk_hip_sync(plonk_hip_ctx *ctx) {
+    PLONK_TRY(bind(ctx));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_malloc(plonk_hip_ctx *ctx, size_t bytes, void **dptr) {
+    PLONK_TRY(bind(ctx));
+    if (!dptr) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_free(plonk_hip_ctx *ctx, void *dptr) {
+    PLONK_TRY(bind(ctx));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    PLONK_HIP_TRY(ctx, hipFree(dptr));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_memcpy_h2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    PLONK_TRY(bind(ctx));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    PLONK_TRY(bind(ctx));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------- SRS
+int plonk_hip_srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
+    PLONK_TRY(bind(ctx));
+    return srs_load_projective(ctx, pts, n);
+}
+
+int plonk_hip_srs_size(plonk_hip_ctx *ctx, size_t *n) {
+    if (!ctx || !n) return PLONK_HIP_ERR_INVALID_ARG;
+    *n = ctx->srs_n;
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out) {
+    PLONK_TRY(bind(ctx));
+    return srs_read(ctx, first, count, out);
+}
+
+int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts) {
+    PLONK_TRY(bind(ctx));
+    return srs_setup(ctx, tau, degree, out_pts);
+}
+
+// ---------------------------------------------------------------------------- commit / open
+int plonk_hip_kzg_commit_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_out) {
+    PLONK_TRY(bind(ctx));
+    if (!d_coeffs || !d_out) return PLONK_HIP_ERR_INVALID_ARG;
+    return msm_run_dev(ctx, (const Fr *)d_coeffs, n, (G1Jac *)d_out);
+}
+
+int plonk_hip_kzg_commit(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t out[18]) {
+    PLONK_TRY(bind(ctx));
+    if (!out || (!coeffs && n)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
+    if (n > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac)));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(ctx->scalars_stage.ptr, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice,
+                                      ctx->stream));
+    PLONK_TRY(msm_run_dev(ctx, (const Fr *)ctx->scalars_stage.ptr, n, (G1Jac *)ctx->out_stage.ptr));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->out_stage.ptr, sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
+                               uint64_t *outs) {
+    if (!coeffs || !ns || !outs) return PLONK_HIP_ERR_INVALID_ARG;
+    for (size_t b = 0; b < batch; b++) PLONK_TRY(plonk_hip_kzg_commit(ctx, coeffs[b], ns[b], outs + 18 * b));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
+                            uint64_t *vs, uint64_t *proofs) {
+    PLONK_TRY(bind(ctx));
+    if (!coeffs || !us || !vs || !proofs) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
+    if (n - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    size_t scr = suffix_scan_scratch_elems(n);
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac)));
+    Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
+    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t k = 0; k < m; k++) {
+        Fr u = load_fr(us + 4 * k);
+        PLONK_TRY(suffix_scan(ctx, d_f, n, u, d_s, d_s + n));
+        // s[0] = f(u); s[1..n) = (f - f(u)) / (X - u)
+        PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, (G1Jac *)ctx->out_stage.ptr));
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * k, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs + 18 * k, ctx->out_stage.ptr, sizeof(G1Jac), hipMemcpyDeviceToHost,
+                                          ctx->stream));
+        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t v[4],
+                       uint64_t proof[18]) {
+    return plonk_hip_kzg_open_many(ctx, coeffs, n, u, 1, v, proof);
+}
+
+int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {
+    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+    ctx->profile = enable != 0;
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]) {
+    PLONK_TRY(bind(ctx));
+    if (!ms || !ctx->profile) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_HIP_TRY(ctx, hipEventSynchronize(ctx->ev[PH_COUNT]));
+    for (int i = 0; i < PH_COUNT; i++) PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return PLONK_HIP_OK;
+}
+
+const char *plonk_hip_msm_phase_name(int i) {
+    static const char *names[PH_COUNT] = {"digits", "sort", "bounds", "accumulate", "fixup", "reduce"};
+    return (i >= 0 && i < PH_COUNT) ? names[i] : "";
+}
+
+int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets) {
+    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    if (window_bits) *window_bits = ctx->plan.c;
+    if (windows) *windows = ctx->plan.nwin;
+    if (buckets) *buckets = ctx->plan.nbuckets;
+    return PLONK_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------- polynomials
+int plonk_hip_fr_scale_by_powers(plonk_hip_ctx *ctx, uint64_t *coeffs, size_t n, const uint64_t w[4]) {
+    PLONK_TRY(bind(ctx));
+    if ((!coeffs && n) || !w) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * sizeof(Fr)));
+    Fr *d = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(scale_by_powers(ctx, d, n, 1, load_fr(w)));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(coeffs, d, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_eval(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t out[4]) {
+    PLONK_TRY(bind(ctx));
+    if ((!coeffs && n) || !u || !out) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) {
+        memset(out, 0, 32);  // the zero polynomial evaluates to zero
+        return PLONK_HIP_OK;
+    }
+    size_t scr = suffix_scan_scratch_elems(n);
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
+    Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
+    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(suffix_scan(ctx, d_f, n, load_fr(u), d_s, d_s + n));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(out, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_div_vanishing(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, size_t k, uint64_t *q) {
+    PLONK_TRY(bind(ctx));
+    if (!f || !q || k == 0) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n <= k) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n - k) * sizeof(Fr)));
+    Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
+    Fr *d_q = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f, f, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(div_vanishing(ctx, d_f, n, k, d_q));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(q, d_q, (n - k) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+static int ntt_host(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, const uint64_t *shift,
+                    int inverse) {
+    PLONK_TRY(bind(ctx));
+    if (!data || log_n > 30) return PLONK_HIP_ERR_INVALID_ARG;
+    size_t total = ((size_t)1 << log_n) * batch;
+    if (total == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, total * sizeof(Fr)));
+    Fr *d = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d, data, total * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    Fr sh;
+    if (shift) sh = load_fr(shift);
+    PLONK_TRY(ntt_dev(ctx, d, log_n, batch, inverse != 0, shift ? &sh : nullptr));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(data, d, total * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, int inverse) {
+    return ntt_host(ctx, data, log_n, batch, nullptr, inverse);
+}
+
+int plonk_hip_fr_coset_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, const uint64_t shift[4],
+                           int inverse) {
+    if (!shift) return PLONK_HIP_ERR_INVALID_ARG;
+    return ntt_host(ctx, data, log_n, batch, shift, inverse);
+}
+
+int plonk_hip_fr_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch, int inverse) {
+    PLONK_TRY(bind(ctx));
+    if (!d_data) return PLONK_HIP_ERR_INVALID_ARG;
+    return ntt_dev(ctx, (Fr *)d_data, log_n, batch, inverse != 0, nullptr);
+}
+
+int plonk_hip_fr_coset_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch,
+                               const uint64_t shift[4], int inverse) {
+    PLONK_TRY(bind(ctx));
+    if (!d_data || !shift) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr sh = load_fr(shift);
+    return ntt_dev(ctx, (Fr *)d_data, log_n, batch, inverse != 0, &sh);
+}
+
+int plonk_hip_fr_quotient_coset_dev(plonk_hip_ctx *ctx, void *d_f_inout, uint32_t log_k, size_t batch,
+                                    int *d_divisible) {
+    PLONK_TRY(bind(ctx));
+    if (!d_f_inout) return PLONK_HIP_ERR_INVALID_ARG;
+    return quotient_coset_dev(ctx, (Fr *)d_f_inout, log_k, batch, d_divisible);
+}
+
+int plonk_hip_fr_quotient_coset(plonk_hip_ctx *ctx, const uint64_t *f, uint32_t log_k, size_t batch, uint64_t *q,
+                                int *divisible) {
+    PLONK_TRY(bind(ctx));
+    if (!f || !q || log_k > 29) return PLONK_HIP_ERR_INVALID_ARG;
+    if (batch == 0) return PLONK_HIP_OK;
+    const size_t k = (size_t)1 << log_k, n = 2 * k;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * batch * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + batch * sizeof(int)));
+    Fr *d = (Fr *)ctx->scratch_c.ptr;
+    int *d_flags = (int *)((char *)ctx->out_stage.ptr + 64 * sizeof(G1Jac));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d, f, n * batch * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(quotient_coset_dev(ctx, d, log_k, batch, d_flags));
+    PLONK_HIP_TRY(ctx, hipMemcpy2DAsync(q, k * sizeof(Fr), d, n * sizeof(Fr), k * sizeof(Fr), batch,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    if (divisible) {
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(divisible, d_flags, batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Library context: one GPU, one stream, the resident SRS window tables and a growable
+// device workspace shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/plonk_hip.h"
+#include "g1.cuh"
+
+namespace plonk {
+
+// A device buffer that only ever grows.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct MsmPlan {
+    int c = 0;           // bits per window
+    int nwin = 0;        // windows = 255/c + 1
+    uint32_t nbuckets = 0;  // 2^(c-1)
+};
+
+enum MsmPhase { PH_DIGITS = 0, PH_SORT, PH_BOUNDS, PH_ACCUM, PH_FIXUP, PH_REDUCE, PH_COUNT };
+
+}  // namespace plonk
+
+struct plonk_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int window_bits_override = 0;
+
+    // SRS: `table` holds plan.nwin levels of srs_n affine points; level w, point i =
+    // [2^(c*w)] P_i at table[w * srs_n + i].
+    size_t srs_n = 0;
+    plonk::MsmPlan plan;
+    plonk::DevBuf table;
+
+    // MSM workspace
+    plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
+    plonk::DevBuf bucket_start, buckets, seg_part, red_a, red_b, red_lw, red_sum_a, red_sum_b;
+    plonk::DevBuf scalars_stage, out_stage;
+    // generic scratch for SRS building and polynomial routines
+    plonk::DevBuf scratch_a, scratch_b, scratch_c;
+    // fixed-base table of the generator for kzg_setup (32 windows x 256 affine multiples)
+    plonk::DevBuf gen_table;
+    // twiddles for the NTT: per log_n forward and inverse tables
+    plonk::DevBuf twiddle[2][33];
+
+    bool profile = false;
+    hipEvent_t ev[plonk::PH_COUNT + 1] = {};
+    float phase_ms[plonk::PH_COUNT] = {};
+};
+
+namespace plonk {
+
+#define PLONK_HIP_TRY(ctx, expr)                                                         \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);       \
+            return _e == hipErrorOutOfMemory ? PLONK_HIP_ERR_OUT_OF_MEMORY : PLONK_HIP_ERR_HIP; \
+        }                                                                                \
+    } while (0)
+
+#define PLONK_TRY(expr)          \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// Grow `b` to at least `bytes` (contents are not preserved).
+int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes);
+void buf_release(DevBuf &b);
+
+// msm.hip
+MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
+// d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out);
+
+// sort.hip
+size_t sort_pairs_temp_bytes(size_t n, int end_bit);
+int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+               uint32_t *vals_out, size_t n, int end_bit, void *temp, size_t temp_bytes);
+
+// srs.hip
+int srs_install_affine(plonk_hip_ctx *ctx, size_t n);  // level 0 already in ctx->table
+int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n);
+int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
+int srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out);
+
+}  // namespace plonk

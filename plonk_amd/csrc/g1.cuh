@@ -85,26 +85,25 @@ PLONK_HD G1Xyzz xyzz_dbl_affine(const Fq &x, const Fq &y) {
     return r;
 }
 
-// acc += (x2, y2) for an affine point that is not the identity (madd-2008-s).
-PLONK_HD void xyzz_madd_xy(G1Xyzz &acc, const Fq &x2, const Fq &y2) {
+// acc += (x2, y2) for an affine point that is not the identity (madd-2008-s), except when
+// (x2, y2) equals acc: then nothing is changed and false is returned -- the caller doubles.
+// Keeping the doubling out of line keeps the hot loop's code and register footprint small.
+PLONK_HD bool xyzz_madd_nodbl(G1Xyzz &acc, const Fq &x2, const Fq &y2) {
     if (xyzz_is_identity(acc)) {
         acc.x = x2;
         acc.y = y2;
         acc.zz = fe_one<FqCfg>();
         acc.zzz = fe_one<FqCfg>();
-        return;
+        return true;
     }
     Fq U2 = fe_mul(x2, acc.zz);
     Fq S2 = fe_mul(y2, acc.zzz);
     Fq P = fe_sub(U2, acc.x);
     Fq R = fe_sub(S2, acc.y);
     if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) {
-            acc = xyzz_dbl_affine(x2, y2);
-        } else {
-            acc = xyzz_identity();
-        }
-        return;
+        if (fe_is_zero(R)) return false;
+        acc = xyzz_identity();
+        return true;
     }
     Fq PP = fe_sqr(P);
     Fq PPP = fe_mul(P, PP);
@@ -115,6 +114,11 @@ PLONK_HD void xyzz_madd_xy(G1Xyzz &acc, const Fq &x2, const Fq &y2) {
     acc.y = Y3;
     acc.zz = fe_mul(acc.zz, PP);
     acc.zzz = fe_mul(acc.zzz, PPP);
+    return true;
+}
+
+PLONK_HD void xyzz_madd_xy(G1Xyzz &acc, const Fq &x2, const Fq &y2) {
+    if (!xyzz_madd_nodbl(acc, x2, y2)) acc = xyzz_dbl_affine(x2, y2);
 }
 
 // acc += (negate ? -p : p); p may be the identity.
@@ -124,10 +128,17 @@ PLONK_HD void xyzz_madd(G1Xyzz &acc, const G1Affine &p, bool negate) {
     xyzz_madd_xy(acc, p.x, y);
 }
 
-// a + b, both XYZZ (add-2008-s).
-PLONK_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
-    if (xyzz_is_identity(a)) return b;
-    if (xyzz_is_identity(b)) return a;
+// out = a + b, both XYZZ (add-2008-s), except when a == b (both non-identity): returns false
+// and leaves out untouched -- the caller doubles.
+PLONK_HD bool xyzz_add_nodbl(G1Xyzz &out, const G1Xyzz &a, const G1Xyzz &b) {
+    if (xyzz_is_identity(a)) {
+        out = b;
+        return true;
+    }
+    if (xyzz_is_identity(b)) {
+        out = a;
+        return true;
+    }
     Fq U1 = fe_mul(a.x, b.zz);
     Fq U2 = fe_mul(b.x, a.zz);
     Fq S1 = fe_mul(a.y, b.zzz);
@@ -135,8 +146,9 @@ PLONK_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
     Fq P = fe_sub(U2, U1);
     Fq R = fe_sub(S2, S1);
     if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) return xyzz_dbl(a);
-        return xyzz_identity();
+        if (fe_is_zero(R)) return false;
+        out = xyzz_identity();
+        return true;
     }
     Fq PP = fe_sqr(P);
     Fq PPP = fe_mul(P, PP);
@@ -146,6 +158,13 @@ PLONK_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
     r.y = fe_sub(fe_mul(R, fe_sub(Q, r.x)), fe_mul(S1, PPP));
     r.zz = fe_mul(fe_mul(a.zz, b.zz), PP);
     r.zzz = fe_mul(fe_mul(a.zzz, b.zzz), PPP);
+    out = r;
+    return true;
+}
+
+PLONK_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
+    G1Xyzz r;
+    if (!xyzz_add_nodbl(r, a, b)) r = xyzz_dbl(a);
     return r;
 }
 

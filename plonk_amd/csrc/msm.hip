@@ -1,0 +1,377 @@
+// G1 multi-scalar multiplication behind kzg_commit / kzg_evaluate: signed-digit bucket method
+// (Pippenger) over resident window tables.
+//
+// The SRS is fixed, so the context keeps [2^(c*w)] P_i for every window w (srs.hip).  All
+// windows then share ONE set of 2^(c-1) buckets and no window is ever shifted by doublings:
+//     sum_i k_i P_i = sum_b (b+1) * B_b,   B_b = sum over (i, w) with |digit_w(k_i)| = b+1
+//                                               of sign * table[w][i].
+// Pipeline (all on the context's stream, no host synchronisation):
+//   1. k_digits      scalars out of Montgomery form, nwin signed digits each -> (bucket, entry)
+//   2. sort_pairs    radix sort of the n*nwin pairs by bucket
+//   3. k_bounds      first sorted position of every bucket
+//   4. k_accumulate  one lane per fixed-length SEGMENT of the sorted list: gathers the affine
+//                    table points and adds them into an XYZZ accumulator (8M + 2S per point).
+//                    Buckets lying wholly inside a segment are written directly; runs cut by a
+//                    segment border are written as partials.  Work per lane is uniform whatever
+//                    the scalar distribution.
+//   5. k_fixup       one lane per bucket that spans several segments: sums its partials
+//   6. k_reduce_*    sum_b (b+1) B_b by recursive 4-bucket chunks:
+//                    S(A, off) = sum_t LW[t] + 4 * S(R, 0) with per-chunk weighted sums LW and
+//                    plain sums R, LDS tree sums of every level's LW, Horner over the levels.
+#include <algorithm>
+#include <cmath>
+
+#include "context.hpp"
+#include "msm_core.cuh"
+
+namespace plonk {
+
+static constexpr int kBlock = 128;
+static constexpr int kChunk = 4;       // bucket-reduction chunk (the "4" in the Horner step)
+static constexpr int kChunkLog = 2;
+static constexpr int kMaxLevels = 16;  // 2^(c-1) buckets, c <= 24 -> 12 levels
+static constexpr int kSumBlock = 256;
+
+// Out-of-line group operations: one copy of each per code object.  The doubling cases are rare
+// (equal operands); the full additions are used by the short serial tails only.
+__device__ __noinline__ void dbl_affine_cold(G1Xyzz &acc, const Fq &x, const Fq &y) { acc = xyzz_dbl_affine(x, y); }
+__device__ __noinline__ void dbl_cold(G1Xyzz &out, const G1Xyzz &a) { out = xyzz_dbl(a); }
+__device__ __noinline__ void add_cold(G1Xyzz &out, const G1Xyzz &a, const G1Xyzz &b) {
+    G1Xyzz r;
+    if (!xyzz_add_nodbl(r, a, b)) dbl_cold(r, a);
+    out = r;
+}
+__device__ __forceinline__ G1Xyzz add_call(const G1Xyzz &a, const G1Xyzz &b) {
+    G1Xyzz r;
+    add_cold(r, a, b);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1. digits
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t srs_n, int c,
+                                               int nwin, uint32_t nbuckets, uint32_t *__restrict__ keys,
+                                               uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr k = fe_from_mont(scalars[i]);
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; w++) {
+        int32_t d = signed_digit(k, w, c, carry);
+        uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        // digit 0 contributes nothing: key nbuckets sorts behind every real bucket
+        uint32_t key = mag == 0 ? nbuckets : mag - 1;
+        uint32_t val = ((uint32_t)w * srs_n + i) | (d < 0 ? 0x80000000u : 0u);
+        size_t at = (size_t)w * n + i;
+        keys[at] = key;
+        vals[at] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. bucket bounds: start[b] = first sorted position with key >= b, b = 0..nbuckets;
+//    start[nbuckets] = number of non-zero digits, start[nbuckets + 1] = total.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t nbuckets,
+                                               uint32_t *__restrict__ start) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    uint32_t k = keys[p];
+    uint32_t first = p == 0 ? 0u : keys[p - 1] + 1u;
+    for (uint32_t b = first; b <= k; b++) start[b] = (uint32_t)p;
+    if (p == total - 1) {
+        for (uint32_t b = k + 1; b <= nbuckets + 1; b++) start[b] = (uint32_t)total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4. accumulate
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint32_t run_end, uint32_t seg_begin,
+                                          size_t seg, const uint32_t *__restrict__ start,
+                                          G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part,
+                                          const G1Xyzz &acc) {
+    if (start[key] == run_begin && start[key + 1] == run_end) {
+        buckets[key] = acc;  // the whole bucket lies inside this segment
+    } else if (run_begin == seg_begin) {
+        part[2 * seg] = acc;  // run touches the segment's first position
+    } else {
+        part[2 * seg + 1] = acc;  // run touches only the segment's last position
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ vals,
+                                                       const uint32_t *__restrict__ start, uint32_t nbuckets,
+                                                       uint32_t seg_len, const G1Affine *__restrict__ table,
+                                                       G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part) {
+    size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nvalid = start[nbuckets];
+    size_t begin64 = seg * seg_len;
+    if (begin64 >= nvalid) return;
+    uint32_t begin = (uint32_t)begin64;
+    size_t end64 = begin64 + seg_len;
+    uint32_t end = end64 < nvalid ? (uint32_t)end64 : nvalid;
+
+    uint32_t cur = keys[begin];
+    uint32_t run_begin = begin;
+    G1Xyzz acc = xyzz_identity();
+    for (uint32_t p = begin; p < end; p++) {
+        uint32_t k = keys[p];
+        if (k != cur) {
+            flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
+            cur = k;
+            run_begin = p;
+            acc = xyzz_identity();
+        }
+        uint32_t v = vals[p];
+        G1Affine pt = table[v & 0x7fffffffu];
+        if (!affine_is_identity(pt)) {
+            Fq y = (v >> 31) ? fe_neg(pt.y) : pt.y;
+            if (!xyzz_madd_nodbl(acc, pt.x, y)) dbl_affine_cold(acc, pt.x, y);
+        }
+    }
+    flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// 5. fix-up: buckets cut by segment borders
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
+                                                  uint32_t seg_len, const G1Xyzz *__restrict__ part,
+                                                  G1Xyzz *__restrict__ buckets) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    uint32_t lo = start[b], hi = start[b + 1];
+    if (lo == hi) {
+        buckets[b] = xyzz_identity();
+        return;
+    }
+    uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
+    if (s0 == s1) return;  // written by k_accumulate
+    G1Xyzz acc = part[2 * (size_t)s0 + (lo == s0 * seg_len ? 0 : 1)];
+    for (uint32_t s = s0 + 1; s <= s1; s++) acc = add_call(acc, part[2 * (size_t)s]);
+    buckets[b] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// 6. reduction  sum_b (b + 1) B_b
+// ------------------------------------------------------------------------------------------
+// One lane per chunk of kChunk consecutive elements of A:
+//   R[t]  = sum_j A[t*kChunk + j]
+//   LW[t] = sum_j (j + off) A[t*kChunk + j]          (off = 1 on the bucket level, else 0)
+__global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz *__restrict__ A, uint32_t n, int off,
+                                                         G1Xyzz *__restrict__ LW, G1Xyzz *__restrict__ R,
+                                                         uint32_t nchunks) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t lo = t * kChunk;
+    uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+    G1Xyzz run = xyzz_identity(), sum = xyzz_identity();
+    for (uint32_t b = hi; b-- > lo;) {
+        run = add_call(run, A[b]);
+        if (b > lo || off) sum = add_call(sum, run);
+    }
+    LW[t] = sum;
+    R[t] = run;
+}
+
+struct SumDesc {
+    uint32_t in_off[kMaxLevels];
+    uint32_t n[kMaxLevels];
+    uint32_t out_off[kMaxLevels];
+};
+
+// Plain sums: block (x, level) adds elements [x*512, x*512+512) of that level's array.
+__global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz *__restrict__ in, G1Xyzz *__restrict__ out,
+                                                        SumDesc d) {
+    __shared__ G1Xyzz sh[kSumBlock];
+    const int lev = blockIdx.y;
+    const uint32_t n = d.n[lev];
+    const uint32_t base = blockIdx.x * (2 * kSumBlock);
+    if (base >= n) return;  // uniform per block
+    const G1Xyzz *src = in + d.in_off[lev];
+    uint32_t i0 = base + threadIdx.x, i1 = i0 + kSumBlock;
+    G1Xyzz acc = i0 < n ? src[i0] : xyzz_identity();
+    if (i1 < n) acc = add_call(acc, src[i1]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = kSumBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            acc = add_call(acc, sh[threadIdx.x + stride]);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[d.out_off[lev] + blockIdx.x] = acc;
+}
+
+// Horner over the level sums: total = s_0 + 4 (s_1 + 4 (s_2 + ...)); Jacobian result.
+__global__ void k_finish(const G1Xyzz *__restrict__ sums, SumDesc d, int nlev, G1Jac *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    G1Xyzz acc = sums[d.in_off[nlev - 1]];
+    for (int l = nlev - 2; l >= 0; l--) {
+        for (int k = 0; k < kChunkLog; k++) dbl_cold(acc, acc);
+        acc = add_call(acc, sums[d.in_off[l]]);
+    }
+    *out = xyzz_to_jac(acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+MsmPlan msm_choose_plan(size_t srs_n, int override_bits) {
+    MsmPlan p;
+    int best = 0;
+    if (override_bits >= 2 && override_bits <= 24) {
+        best = override_bits;
+    } else {
+        // Cost in "bucket additions": the accumulation runs ~2^18 lanes at once; the
+        // reduction is a serial tail whose depth grows with c.
+        double best_cost = 1e300;
+        const double lanes = 262144.0;
+        for (int c = 4; c <= 22; c++) {
+            double nwin = msm_num_windows(c);
+            double nb = std::ldexp(1.0, c - 1);
+            double total = (double)srs_n * nwin;
+            double per_bucket = total / nb;
+            double seg = std::max(std::sqrt(per_bucket), total / 1048576.0);
+            double accumulate = std::max(total / lanes, seg);
+            double fixup = 1.4 * std::max(per_bucket / seg, nb * (per_bucket / seg) / lanes);
+            double reduce_work = 1.4 * 3.0 * nb / lanes;
+            double reduce_depth = 1.4 * (8.0 * std::ceil((c - 1) / 2.0) + 18.0 + 1.5 * (c - 1));
+            double cost = accumulate + fixup + reduce_work + reduce_depth;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = c;
+            }
+        }
+    }
+    // table index (w * srs_n + i) must fit in 31 bits
+    while (best < 24 && (double)srs_n * msm_num_windows(best) >= 2147483648.0) best++;
+    p.c = best;
+    p.nwin = msm_num_windows(best);
+    p.nbuckets = 1u << (best - 1);
+    return p;
+}
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+static void record(plonk_hip_ctx *ctx, int i) {
+    if (ctx->profile) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out) {
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
+    if (n > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    const MsmPlan &pl = ctx->plan;
+    const size_t total = n * (size_t)pl.nwin;
+    if (total >= 0xfffffff0ull) return PLONK_HIP_ERR_INVALID_ARG;
+    const uint32_t nb = pl.nbuckets;
+    hipStream_t st = ctx->stream;
+
+    // segment length: balance accumulation depth against fix-up depth for small inputs, keep
+    // about 2^20 segments for large ones
+    const double per_bucket = (double)total / nb;
+    uint32_t seg_len = (uint32_t)std::max<double>(
+        1.0, std::max(std::ceil(std::sqrt(per_bucket)), std::ceil((double)total / 1048576.0)));
+    const size_t nseg = (total + seg_len - 1) / seg_len;
+
+    size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_a, total * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_b, total * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_a, total * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_b, total * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
+    PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz)));
+
+    uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
+    uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
+    uint32_t *start = (uint32_t *)ctx->bucket_start.ptr;
+    G1Xyzz *buckets = (G1Xyzz *)ctx->buckets.ptr;
+    G1Xyzz *part = (G1Xyzz *)ctx->seg_part.ptr;
+    const G1Affine *table = (const G1Affine *)ctx->table.ptr;
+
+    record(ctx, PH_DIGITS);
+    hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
+                       pl.c, pl.nwin, nb, keys_a, vals_a);
+    record(ctx, PH_SORT);
+    PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
+    record(ctx, PH_BOUNDS);
+    hipLaunchKernelGGL(k_bounds, dim3(cdiv(total, 256)), dim3(256), 0, st, keys_b, total, nb, start);
+    record(ctx, PH_ACCUM);
+    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
+                       seg_len, table, buckets, part);
+    record(ctx, PH_FIXUP);
+    hipLaunchKernelGGL(k_fixup, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, st, start, nb, seg_len, part, buckets);
+    record(ctx, PH_REDUCE);
+
+    // ---- reduction levels
+    uint32_t level_n[kMaxLevels + 1];
+    int nlev = 0;
+    level_n[0] = nb;
+    size_t lw_total = 0;
+    while (true) {
+        uint32_t nchunks = (level_n[nlev] + kChunk - 1) / kChunk;
+        level_n[nlev + 1] = nchunks;
+        lw_total += nchunks;
+        nlev++;
+        if (nchunks <= 1) break;
+    }
+    if (nlev > kMaxLevels) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_TRY(buf_reserve(ctx, ctx->red_a, (size_t)level_n[1] * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_b, (size_t)(nlev > 1 ? level_n[2] : 1) * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_lw, lw_total * sizeof(G1Xyzz)));
+    G1Xyzz *lw = (G1Xyzz *)ctx->red_lw.ptr;
+    SumDesc desc = {};
+    {
+        const G1Xyzz *A = buckets;
+        uint32_t off = 0;
+        for (int l = 0; l < nlev; l++) {
+            G1Xyzz *Rbuf = (G1Xyzz *)((l & 1) ? ctx->red_b.ptr : ctx->red_a.ptr);
+            uint32_t nchunks = level_n[l + 1];
+            hipLaunchKernelGGL(k_reduce_level, dim3(cdiv(nchunks, kBlock)), dim3(kBlock), 0, st, A, level_n[l],
+                               l == 0 ? 1 : 0, lw + off, Rbuf, nchunks);
+            desc.in_off[l] = off;
+            desc.n[l] = nchunks;
+            off += nchunks;
+            A = Rbuf;
+        }
+    }
+    // ---- plain sums of every level's LW array
+    size_t max_blocks_total = 0;
+    for (int l = 0; l < nlev; l++) max_blocks_total += cdiv(desc.n[l], 2 * kSumBlock);
+    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_a, max_blocks_total * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_b, max_blocks_total * sizeof(G1Xyzz)));
+    const G1Xyzz *in = lw;
+    G1Xyzz *outs[2] = {(G1Xyzz *)ctx->red_sum_a.ptr, (G1Xyzz *)ctx->red_sum_b.ptr};
+    int flip = 0;
+    while (true) {
+        uint32_t max_n = 0, max_blocks = 0, off = 0;
+        for (int l = 0; l < nlev; l++) {
+            uint32_t blocks = cdiv(desc.n[l], 2 * kSumBlock);
+            desc.out_off[l] = off;
+            off += blocks;
+            max_n = std::max(max_n, desc.n[l]);
+            max_blocks = std::max(max_blocks, blocks);
+        }
+        if (max_n <= 1) break;
+        hipLaunchKernelGGL(k_sum_pass, dim3(max_blocks, nlev), dim3(kSumBlock), 0, st, in, outs[flip], desc);
+        for (int l = 0; l < nlev; l++) {
+            desc.in_off[l] = desc.out_off[l];
+            desc.n[l] = cdiv(desc.n[l], 2 * kSumBlock);
+        }
+        in = outs[flip];
+        flip ^= 1;
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, in, desc, nlev, d_out);
+    record(ctx, PH_COUNT);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+}  // namespace plonk

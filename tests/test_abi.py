@@ -1,0 +1,26 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/plonk_hip.h declares."""
+import os
+import re
+
+import plonk_amd
+from plonk_amd import lib as plib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
+    declared = set(re.findall(r"\b(plonk_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = plonk_amd.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(plib.SIGNATURES)
+
+
+def test_error_strings():
+    lib = plonk_amd.load_library()
+    assert lib.plonk_hip_strerror(0) == b"ok"
+    # same text as the reference's CommitError::CommitFailed (plonk/src/common/kzg.rs:13)
+    assert lib.plonk_hip_strerror(-1) == b"Length of tau_powers_g1 must be at least equal to degree of polynomial + 1"
+    assert lib.plonk_hip_msm_phase_name(3) == b"accumulate"

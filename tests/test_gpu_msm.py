@@ -1,0 +1,165 @@
+"""GPU parity: the G1 MSM behind kzg_commit / kzg_evaluate and kzg_setup, through the C ABI,
+against the oracle and the reference's golden vectors.  Bit-exact (compressed encodings)."""
+import random
+
+import numpy as np
+import pytest
+
+import plonk_amd
+from oracle import capi as c
+from oracle import pyref as o
+from tests.gpu_util import backend, compress, rand_fr, same_point  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden_srs(golden):
+    setup = o.load_setup_json(golden["srs"])
+    return c.g1_to_limbs(setup.gp.tau_powers_g1)
+
+
+@pytest.mark.parametrize("window_bits", [0, 2, 3, 8, 13, 16])
+def test_verification_key_commitments(backend, golden, golden_srs, window_bits):
+    # com_S (3 coefficients) and com_W (12) of plonk/data/verification_key.json
+    backend.set_window_bits(window_bits)
+    backend.srs_load_projective(golden_srs)
+    assert backend.srs_size() == 22
+    for name in "SW":
+        sc = c.fr_to_mont([int(x) for x in golden["proving_key"][name]])
+        assert compress(backend.kzg_commit(sc)).hex() == golden["verification_key"]["com_" + name]
+    backend.set_window_bits(0)
+
+
+def test_srs_round_trip(backend, golden_srs):
+    backend.srs_load_projective(golden_srs)
+    back = backend.srs_read(0, 22)
+    assert c.g1_compress(back) == c.g1_compress(golden_srs)
+
+
+def test_commit_errors_match_reference(backend, golden_srs):
+    backend.srs_load_projective(golden_srs)
+    rnd = random.Random(1)
+    with pytest.raises(plonk_amd.CommitError):  # plonk/tests/kzg_tests.rs:71-93
+        backend.kzg_commit(c.fr_to_mont(rand_fr(rnd, 23)))
+    with pytest.raises(plonk_amd.ReferencePanic):  # empty reduce unwrap, kzg.rs:57-58
+        backend.kzg_commit(np.zeros((0, 4), dtype=np.uint64))
+    with pytest.raises(plonk_amd.ReferencePanic):  # constant polynomial, kzg.rs:85
+        backend.kzg_evaluate(c.fr_to_mont([5]), c.fr_to_mont([3])[0])
+    fresh = plonk_amd.Backend(device=0)
+    with pytest.raises(plonk_amd.PlonkHipError):
+        fresh.kzg_commit(c.fr_to_mont([1, 2]))
+    fresh.close()
+
+
+def test_kzg_setup_matches_sequential_chain(backend):
+    rnd = random.Random(2)
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    degree = 200
+    got = backend.kzg_setup(tau, degree)
+    want = c.kzg_setup(tau, degree)  # plonk/src/common/kzg.rs:29-36
+    assert c.g1_compress(got) == c.g1_compress(want)
+    assert backend.srs_size() == degree + 1
+    assert c.g1_compress(backend.srs_read(0, degree + 1)) == c.g1_compress(want)
+
+
+@pytest.mark.parametrize("n,window_bits", [(1, 0), (2, 4), (257, 0), (1000, 7), (1000, 11), (4096, 0)])
+def test_commit_random_polynomials(backend, n, window_bits):
+    rnd = random.Random(100 + n + window_bits)
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    backend.set_window_bits(window_bits)
+    srs = backend.kzg_setup(tau, n - 1)
+    backend.set_window_bits(0)
+    sc = c.fr_to_mont(rand_fr(rnd, n))
+    got = backend.kzg_commit(sc)
+    # plonk/tests/kzg_tests.rs:36-69: commit == G * f(tau)
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+    if n <= 1000:
+        assert same_point(got, c.msm_naive(srs, sc, threads=4))
+    # shorter polynomial against the same SRS
+    if n > 2:
+        m = n // 2 + 1
+        assert same_point(backend.kzg_commit(sc[:m]), c.g1_mul(c.g1_generator(), c.fr_eval(sc[:m], tau)))
+
+
+def test_commit_edge_scalars_and_points(backend):
+    rnd = random.Random(3)
+    n = 300
+    g = c.g1_generator()
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    srs = c.kzg_setup(tau, n - 1)
+    # identity points and repeated points inside the SRS
+    srs[7] = c.g1_identity()
+    srs[8] = srs[9]
+    srs[20] = c.g1_neg(srs[21])
+    backend.srs_load_projective(srs)
+    cases = {
+        "zeros": [0] * n,
+        "ones": [1] * n,
+        "minus_one": [o.R - 1] * n,
+        "equal": [rnd.randrange(o.R)] * n,
+        "sparse": [rnd.randrange(o.R) if i % 16 else 0 for i in range(n)],
+        "small": [rnd.randrange(4) for _ in range(n)],
+        "top_heavy": [o.R - 1 - rnd.randrange(1000) for _ in range(n)],
+    }
+    for name, vals in cases.items():
+        sc = c.fr_to_mont(vals)
+        assert same_point(backend.kzg_commit(sc), c.msm_naive(srs, sc, threads=4)), name
+    assert compress(backend.kzg_commit(c.fr_to_mont(cases["zeros"]))) == o.g1_compress(o.G1_IDENTITY)
+
+
+def test_open_matches_reference_definition(backend):
+    rnd = random.Random(4)
+    for n in (2, 3, 65, 300, 5000):
+        tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+        backend.kzg_setup(tau, n - 1, want_points=False)
+        f = rand_fr(rnd, n)
+        u = rnd.randrange(o.R)
+        v, proof = backend.kzg_evaluate(c.fr_to_mont(f), c.fr_to_mont([u])[0])
+        assert c.fr_from_mont(v)[0] == o.poly_eval(f, u)  # kzg_tests.rs:140
+        q, _ = o.poly_divmod(o.poly_sub(f, [o.poly_eval(f, u)]), [(-u) % o.R, 1])
+        q_at_tau = c.fr_eval(c.fr_to_mont(q), tau)
+        assert same_point(proof, c.g1_mul(c.g1_generator(), q_at_tau))  # kzg_tests.rs:141-145
+    # several openings of one polynomial
+    us = rand_fr(rnd, 3)
+    vs, proofs = backend.kzg_evaluate_many(c.fr_to_mont(f), c.fr_to_mont(us))
+    for i, uu in enumerate(us):
+        v1, p1 = backend.kzg_evaluate(c.fr_to_mont(f), c.fr_to_mont([uu])[0])
+        assert np.array_equal(v1, vs[i]) and same_point(p1, proofs[i])
+
+
+def test_commit_2_16_points(backend):
+    # BASELINE config "single KZG commit: 2^16-point G1 MSM against a synthetic SRS"
+    rnd = random.Random(5)
+    n = 1 << 16
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    srs = backend.kzg_setup(tau, n - 1)
+    # spot-check the generated SRS against independent scalar multiplications
+    g = c.g1_generator()
+    for i in (0, 1, 2, 12345, n - 1):
+        assert same_point(srs[i], c.g1_mul(g, c.fr_to_mont([pow(c.fr_from_mont(tau)[0], i, o.R)])[0]))
+    sc = np.frombuffer(rnd.randbytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)  # any value below r is a valid Montgomery residue
+    got = backend.kzg_commit(sc)
+    assert same_point(got, c.g1_mul(g, c.fr_eval(sc, tau)))
+    aff = c.g1_to_affine(srs)
+    assert same_point(got, c.msm_pippenger(aff, sc, c=13, threads=8))
+    # device-resident entry point
+    d_sc = backend.to_device(sc)
+    d_out = backend.malloc(144)
+    backend.kzg_commit_dev(d_sc, n, d_out)
+    backend.sync()
+    assert same_point(backend.from_device(d_out, (18,)), got)
+    backend.free(d_sc)
+    backend.free(d_out)
+
+
+def test_commit_2_20_points_known_answer(backend):
+    rnd = random.Random(6)
+    n = 1 << 20
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    sc = np.frombuffer(rnd.randbytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    got = backend.kzg_commit(sc)
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))

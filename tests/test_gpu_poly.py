@@ -1,0 +1,99 @@
+"""GPU parity: Fr transforms over Omega, coset transforms, quotient by Z_Omega, evaluation and
+coefficient scaling, through the C ABI, against the oracle.  Bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import capi as c
+from oracle import pyref as o
+from tests.gpu_util import backend, rand_fr  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 9, 10, 11, 13])
+def test_ntt_matches_oracle(backend, log_n):
+    rnd = random.Random(50 + log_n)
+    n = 1 << log_n
+    batch = 3
+    co = c.fr_to_mont(rand_fr(rnd, n * batch)).reshape(batch, n, 4)
+    ev = backend.fr_ntt(co)
+    for b in range(batch):
+        assert np.array_equal(ev[b], c.fr_ntt(co[b]))
+    assert np.array_equal(backend.fr_ntt(ev, inverse=True), co)
+    if 1 <= log_n <= 5:
+        # the definition: evaluations over construct_Omega(n) / interpolate_polynomial
+        ints = c.fr_from_mont(co[0])
+        Om = o.construct_Omega(n)
+        assert c.fr_from_mont(ev[0]) == [o.poly_eval(ints, x) for x in Om]
+        assert o.poly_trim(c.fr_from_mont(backend.interpolate_over_omega(ev[0]))) == o.interpolate_polynomial(
+            Om, c.fr_from_mont(ev[0]))
+
+
+def test_coset_ntt(backend):
+    rnd = random.Random(60)
+    n = 256
+    co = rand_fr(rnd, n)
+    shift = rnd.randrange(2, o.R)
+    ev = backend.fr_ntt(c.fr_to_mont(co), shift=c.fr_to_mont([shift])[0])
+    w = o.root_of_unity(n)
+    assert c.fr_from_mont(ev) == [o.poly_eval(co, shift * pow(w, j, o.R) % o.R) for j in range(n)]
+    back = backend.fr_ntt(ev, inverse=True, shift=c.fr_to_mont([shift])[0])
+    assert c.fr_from_mont(back) == co
+
+
+def test_ntt_2_20_round_trip_and_oracle(backend):
+    rnd = random.Random(61)
+    n = 1 << 20
+    batch = 2
+    data = np.frombuffer(rnd.randbytes(batch * n * 32), dtype=np.uint64).reshape(batch, n, 4).copy()
+    data[:, :, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    ev = backend.fr_ntt(data)
+    assert np.array_equal(ev[0], c.fr_ntt(data[0]))
+    assert np.array_equal(backend.fr_ntt(ev, inverse=True), data)
+
+
+def test_eval_and_scaling(backend):
+    rnd = random.Random(62)
+    for n in (1, 2, 100, 257, 70000):
+        f = rand_fr(rnd, n)
+        u = rnd.randrange(o.R)
+        got = backend.fr_eval(c.fr_to_mont(f), c.fr_to_mont([u])[0])
+        assert c.fr_from_mont(got)[0] == o.poly_eval(f, u)
+    f = rand_fr(rnd, 3000)
+    w = rnd.randrange(o.R)
+    got = c.fr_from_mont(backend.compose_with_scaling(c.fr_to_mont(f), c.fr_to_mont([w])[0]))
+    assert got == [x * pow(w, i, o.R) % o.R for i, x in enumerate(f)]
+    small = rand_fr(rnd, 12)
+    assert o.poly_trim(c.fr_from_mont(backend.compose_with_scaling(c.fr_to_mont(small), c.fr_to_mont([w])[0]))) == \
+        o.compose_polynomials(small, [0, w])  # polynomials.rs:80-113
+
+
+def test_div_vanishing_is_long_division(backend):
+    rnd = random.Random(63)
+    for n, k in ((25, 12), (13, 12), (100, 7), (2048, 1024), (5000, 1)):
+        f = rand_fr(rnd, n)  # not divisible: remainder is dropped, protocols.rs:162-165
+        q = c.fr_from_mont(backend.compute_q_zero_test(k, c.fr_to_mont(f)))
+        assert o.poly_trim(q) == o.compute_q_zero_test(k, f)
+    assert backend.compute_q_zero_test(12, c.fr_to_mont(rand_fr(rnd, 5))).shape[0] == 0
+    # divisible case: exact
+    qs = rand_fr(rnd, 40)
+    f = o.poly_mul(qs, o.construct_vanishing_polynomial(16))
+    assert o.poly_trim(c.fr_from_mont(backend.compute_q_zero_test(16, c.fr_to_mont(f)))) == o.poly_trim(qs)
+
+
+@pytest.mark.parametrize("log_k", [1, 4, 10, 12])
+def test_quotient_coset(backend, log_k):
+    rnd = random.Random(64 + log_k)
+    k = 1 << log_k
+    batch = 3
+    qs = [rand_fr(rnd, k) for _ in range(batch)]
+    fs = [[(-x) % o.R for x in q] + q for q in qs]  # q * (X^k - 1)
+    fs[2][0] = (fs[2][0] + 1) % o.R  # not divisible
+    f = c.fr_to_mont([x for row in fs for x in row]).reshape(batch, 2 * k, 4)
+    q, ok = backend.quotient_coset(f)
+    assert ok == [True, True, False]
+    for b in range(2):
+        assert c.fr_from_mont(q[b]) == qs[b]
+        assert o.poly_trim(qs[b]) == o.compute_q_zero_test(k, fs[b])
