@@ -89,6 +89,10 @@ int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t 
  * NULL, returns it ((degree+1) x 18).  The reference's own tau is `Fr::rand(test_rng())`;
  * drawing it stays on the caller's side.  tau_g2 (kzg.rs:39) is not produced here. */
 int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
+/* The slice [tau^first .. tau^(first+count-1)]G of the same sequence: the SRS range one GPU
+ * holds when a large commitment is sharded by point range (one context per GPU). */
+int plonk_hip_kzg_setup_range(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t count,
+                              uint64_t *out_pts);
 
 /* ----------------------------------------------------------------------------------------
  * Commit / open -- the G1 MSM
@@ -103,6 +107,10 @@ int plonk_hip_kzg_commit_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n,
  * polynomials against the same SRS.  outs = batch x 18. */
 int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
                                uint64_t *outs);
+
+/* d_out = sum of n Jacobian points in device memory (n x 18 -> 18): combines the per-GPU
+ * partial commitments after they have been gathered (the `+` of kzg.rs:57 across shards). */
+int plonk_hip_g1_sum_dev(plonk_hip_ctx *ctx, const void *d_pts, size_t n, void *d_out);
 
 /* `kzg_evaluate(gp, f, u)` (kzg.rs:63-88): v = f(u); q = (f - v) / (X - u);
  * proof = sum_i q_i * tau_powers_g1[i].  n = coeffs.len().
@@ -121,6 +129,9 @@ int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable);
 int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]);
 const char *plonk_hip_msm_phase_name(int i);
+/* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
+ * integer multiply-add `v_mad_u64_u32` issued from registers only; measured, takes ~50 ms. */
+int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
 /* Window plan in force: bits per window, windows, buckets. */
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
 

@@ -114,6 +114,12 @@ class Backend:
         self._check(self._lib.plonk_hip_msm_phase_ms(self._ctx, ms))
         return {self._lib.plonk_hip_msm_phase_name(i).decode(): float(ms[i]) for i in range(6)}
 
+    def bench_mad_rate(self):
+        """Measured peak of the integer multiply-add (mads per second, whole GPU)."""
+        v = ctypes.c_double()
+        self._check(self._lib.plonk_hip_bench_mad_rate(self._ctx, ctypes.byref(v)))
+        return v.value
+
     def msm_plan(self):
         c, w, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
         self._check(self._lib.plonk_hip_msm_plan(self._ctx, ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)))
@@ -141,6 +147,17 @@ class Backend:
         out = np.empty((degree + 1, 18), dtype=np.uint64) if want_points else None
         self._check(self._lib.plonk_hip_kzg_setup(self._ctx, _u64(tau), degree, _u64(out) if want_points else None))
         return out
+
+    def kzg_setup_range(self, tau, first, count, want_points=False):
+        """SRS slice [tau^first .. tau^(first+count-1)]G for point-range sharding."""
+        tau = _fr(tau).reshape(4)
+        out = np.empty((count, 18), dtype=np.uint64) if want_points else None
+        self._check(self._lib.plonk_hip_kzg_setup_range(self._ctx, _u64(tau), first, count,
+                                                        _u64(out) if want_points else None))
+        return out
+
+    def g1_sum_dev(self, d_pts, n, d_out):
+        self._check(self._lib.plonk_hip_g1_sum_dev(self._ctx, d_pts, n, d_out))
 
     # ------------------------------------------------------------------ commit / open
     def kzg_commit(self, coeffs):

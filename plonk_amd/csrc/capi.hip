@@ -74,7 +74,7 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
-                      &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->red_a,
+                      &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
                       &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table};
     for (DevBuf *b : bufs) buf_release(*b);
@@ -165,7 +165,19 @@ int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t 
 
 int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts) {
     PLONK_TRY(bind(ctx));
-    return srs_setup(ctx, tau, degree, out_pts);
+    return srs_setup(ctx, tau, 0, degree + 1, out_pts);
+}
+
+int plonk_hip_kzg_setup_range(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t count,
+                              uint64_t *out_pts) {
+    PLONK_TRY(bind(ctx));
+    return srs_setup(ctx, tau, first, count, out_pts);
+}
+
+int plonk_hip_g1_sum_dev(plonk_hip_ctx *ctx, const void *d_pts, size_t n, void *d_out) {
+    PLONK_TRY(bind(ctx));
+    if (!d_pts || !d_out) return PLONK_HIP_ERR_INVALID_ARG;
+    return g1_sum_dev(ctx, (const G1Jac *)d_pts, n, (G1Jac *)d_out);
 }
 
 // ---------------------------------------------------------------------------- commit / open
@@ -228,6 +240,12 @@ int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n
 int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t v[4],
                        uint64_t proof[18]) {
     return plonk_hip_kzg_open_many(ctx, coeffs, n, u, 1, v, proof);
+}
+
+int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {
+    PLONK_TRY(bind(ctx));
+    if (!mads_per_second) return PLONK_HIP_ERR_INVALID_ARG;
+    return bench_mad_rate(ctx, mads_per_second);
 }
 
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {

@@ -42,7 +42,7 @@ struct plonk_hip_ctx {
 
     // MSM workspace
     plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
-    plonk::DevBuf bucket_start, buckets, seg_part, red_a, red_b, red_lw, red_sum_a, red_sum_b;
+    plonk::DevBuf bucket_start, buckets, seg_part, big_list, red_a, red_b, red_lw, red_sum_a, red_sum_b;
     plonk::DevBuf scalars_stage, out_stage;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
@@ -81,16 +81,21 @@ void buf_release(DevBuf &b);
 MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
 // d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
 int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out);
+// d_out = sum of n Jacobian points in device memory (the gathered per-GPU partial results)
+int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out);
 
 // sort.hip
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
                uint32_t *vals_out, size_t n, int end_bit, void *temp, size_t temp_bytes);
 
+// microbench.hip
+int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
+
 // srs.hip
 int srs_install_affine(plonk_hip_ctx *ctx, size_t n);  // level 0 already in ctx->table
 int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n);
-int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
+int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t n, uint64_t *out_pts);
 int srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out);
 
 }  // namespace plonk

@@ -33,19 +33,9 @@ static constexpr int kMaxLevels = 16;  // 2^(c-1) buckets, c <= 24 -> 12 levels
 static constexpr int kSumBlock = 256;
 
 // Out-of-line group operations: one copy of each per code object.  The doubling cases are rare
-// (equal operands); the full additions are used by the short serial tails only.
+// (equal operands).
 __device__ __noinline__ void dbl_affine_cold(G1Xyzz &acc, const Fq &x, const Fq &y) { acc = xyzz_dbl_affine(x, y); }
 __device__ __noinline__ void dbl_cold(G1Xyzz &out, const G1Xyzz &a) { out = xyzz_dbl(a); }
-__device__ __noinline__ void add_cold(G1Xyzz &out, const G1Xyzz &a, const G1Xyzz &b) {
-    G1Xyzz r;
-    if (!xyzz_add_nodbl(r, a, b)) dbl_cold(r, a);
-    out = r;
-}
-__device__ __forceinline__ G1Xyzz add_call(const G1Xyzz &a, const G1Xyzz &b) {
-    G1Xyzz r;
-    add_cold(r, a, b);
-    return r;
-}
 
 // ------------------------------------------------------------------------------------------
 // 1. digits
@@ -138,9 +128,29 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restric
 // ------------------------------------------------------------------------------------------
 // 5. fix-up: buckets cut by segment borders
 // ------------------------------------------------------------------------------------------
+// Full XYZZ addition with the (rare) equal-operands case out of line: one inlined copy per
+// kernel keeps the serial tails short without blowing up the code object.
+__device__ __forceinline__ G1Xyzz add_inline(const G1Xyzz &a, const G1Xyzz &b) {
+    G1Xyzz r;
+    if (!xyzz_add_nodbl(r, a, b)) dbl_cold(r, a);
+    return r;
+}
+
+// Partial j (0-based) of a bucket whose run starts at sorted position lo: segment s0 + j;
+// only the first partial can sit in the "touches the segment end" slot.
+__device__ __forceinline__ const G1Xyzz *partial_of(const G1Xyzz *part, uint32_t s0, uint32_t j, uint32_t lo,
+                                                    uint32_t seg_len) {
+    size_t s = (size_t)s0 + j;
+    return part + 2 * s + ((j == 0 && lo != s0 * seg_len) ? 1 : 0);
+}
+
+// One lane per bucket.  Buckets with more than serial_max partials (skewed digit
+// distributions: the narrow top window, repeated scalars) are queued for k_fixup_big.
 __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                   uint32_t seg_len, const G1Xyzz *__restrict__ part,
-                                                  G1Xyzz *__restrict__ buckets) {
+                                                  G1Xyzz *__restrict__ buckets, uint32_t serial_max,
+                                                  uint32_t *__restrict__ big_count,
+                                                  uint32_t *__restrict__ big_list) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     uint32_t lo = start[b], hi = start[b + 1];
@@ -150,9 +160,66 @@ __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ s
     }
     uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
     if (s0 == s1) return;  // written by k_accumulate
-    G1Xyzz acc = part[2 * (size_t)s0 + (lo == s0 * seg_len ? 0 : 1)];
-    for (uint32_t s = s0 + 1; s <= s1; s++) acc = add_call(acc, part[2 * (size_t)s]);
+    uint32_t cnt = s1 - s0 + 1;
+    if (cnt > serial_max) {
+        big_list[atomicAdd(big_count, 1u)] = b;
+        return;
+    }
+    G1Xyzz acc = *partial_of(part, s0, 0, lo, seg_len);
+    for (uint32_t j = 1; j < cnt; j++) acc = add_inline(acc, *partial_of(part, s0, j, lo, seg_len));
     buckets[b] = acc;
+}
+
+// Sum of `cnt` points fetched through `at(j)` by one 256-lane block: strided partial sums,
+// then an LDS tree.  The result is valid in lane 0.  One inlined addition serves both stages.
+template <class At>
+__device__ __forceinline__ G1Xyzz block_sum(uint32_t cnt, G1Xyzz *sh, At at) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t strided = (cnt + kSumBlock - 1) / kSumBlock;  // uniform over the block
+    G1Xyzz acc = xyzz_identity();
+    const uint32_t steps = strided + 8;  // 8 = log2(kSumBlock) tree levels
+    for (uint32_t step = 0; step < steps; step++) {
+        const G1Xyzz *src = nullptr;
+        if (step < strided) {
+            uint32_t j = step * kSumBlock + t;
+            if (j < cnt) src = at(j);
+        } else {
+            uint32_t stride = (kSumBlock / 2) >> (step - strided);
+            if (step == strided) {
+                sh[t] = acc;
+                __syncthreads();
+            }
+            if (t < stride) src = &sh[t + stride];
+        }
+        if (src) {
+            G1Xyzz o = *src;
+            acc = add_inline(acc, o);
+        }
+        if (step >= strided) {
+            __syncthreads();  // every read of this level is done
+            sh[t] = acc;
+            __syncthreads();
+        }
+    }
+    return acc;
+}
+
+// One block per queued bucket (grid-stride over the queue).
+__global__ __launch_bounds__(kSumBlock) void k_fixup_big(const uint32_t *__restrict__ start, uint32_t seg_len,
+                                                         const G1Xyzz *__restrict__ part,
+                                                         G1Xyzz *__restrict__ buckets,
+                                                         const uint32_t *__restrict__ big_count,
+                                                         const uint32_t *__restrict__ big_list) {
+    __shared__ G1Xyzz sh[kSumBlock];
+    const uint32_t count = *big_count;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        uint32_t b = big_list[i];
+        uint32_t lo = start[b], hi = start[b + 1];
+        uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
+        G1Xyzz acc = block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
+        if (threadIdx.x == 0) buckets[b] = acc;
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -161,6 +228,8 @@ __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ s
 // One lane per chunk of kChunk consecutive elements of A:
 //   R[t]  = sum_j A[t*kChunk + j]
 //   LW[t] = sum_j (j + off) A[t*kChunk + j]          (off = 1 on the bucket level, else 0)
+// by the running-sum recurrence run += A[b]; sum += run, highest b first.  Both updates go
+// through one inlined addition with selected operands.
 __global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz *__restrict__ A, uint32_t n, int off,
                                                          G1Xyzz *__restrict__ LW, G1Xyzz *__restrict__ R,
                                                          uint32_t nchunks) {
@@ -169,9 +238,19 @@ __global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz *__restric
     uint32_t lo = t * kChunk;
     uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
     G1Xyzz run = xyzz_identity(), sum = xyzz_identity();
-    for (uint32_t b = hi; b-- > lo;) {
-        run = add_call(run, A[b]);
-        if (b > lo || off) sum = add_call(sum, run);
+    const uint32_t steps = 2 * (hi - lo);
+    for (uint32_t step = 0; step < steps; step++) {
+        uint32_t b = hi - 1 - (step >> 1);
+        bool to_run = (step & 1) == 0;
+        if (!to_run && b == lo && !off) break;  // weight 0 for the chunk's first element
+        G1Xyzz x = to_run ? run : sum;
+        G1Xyzz y = to_run ? A[b] : run;
+        G1Xyzz r = add_inline(x, y);
+        if (to_run) {
+            run = r;
+        } else {
+            sum = r;
+        }
     }
     LW[t] = sum;
     R[t] = run;
@@ -183,27 +262,20 @@ struct SumDesc {
     uint32_t out_off[kMaxLevels];
 };
 
-// Plain sums: block (x, level) adds elements [x*512, x*512+512) of that level's array.
+static constexpr uint32_t kSumPerBlock = 4 * kSumBlock;
+
+// Plain sums: block (x, level) adds elements [x*kSumPerBlock, (x+1)*kSumPerBlock) of that
+// level's array.
 __global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz *__restrict__ in, G1Xyzz *__restrict__ out,
                                                         SumDesc d) {
     __shared__ G1Xyzz sh[kSumBlock];
     const int lev = blockIdx.y;
     const uint32_t n = d.n[lev];
-    const uint32_t base = blockIdx.x * (2 * kSumBlock);
+    const uint32_t base = blockIdx.x * kSumPerBlock;
     if (base >= n) return;  // uniform per block
-    const G1Xyzz *src = in + d.in_off[lev];
-    uint32_t i0 = base + threadIdx.x, i1 = i0 + kSumBlock;
-    G1Xyzz acc = i0 < n ? src[i0] : xyzz_identity();
-    if (i1 < n) acc = add_call(acc, src[i1]);
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = kSumBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) {
-            acc = add_call(acc, sh[threadIdx.x + stride]);
-            sh[threadIdx.x] = acc;
-        }
-        __syncthreads();
-    }
+    const G1Xyzz *src = in + d.in_off[lev] + base;
+    uint32_t cnt = n - base < kSumPerBlock ? n - base : kSumPerBlock;
+    G1Xyzz acc = block_sum(cnt, sh, [&](uint32_t j) { return src + j; });
     if (threadIdx.x == 0) out[d.out_off[lev] + blockIdx.x] = acc;
 }
 
@@ -212,9 +284,17 @@ __global__ void k_finish(const G1Xyzz *__restrict__ sums, SumDesc d, int nlev, G
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     G1Xyzz acc = sums[d.in_off[nlev - 1]];
     for (int l = nlev - 2; l >= 0; l--) {
-        for (int k = 0; k < kChunkLog; k++) dbl_cold(acc, acc);
-        acc = add_call(acc, sums[d.in_off[l]]);
+        for (int k = 0; k < kChunkLog; k++) acc = xyzz_dbl(acc);
+        acc = add_inline(acc, sums[d.in_off[l]]);
     }
+    *out = xyzz_to_jac(acc);
+}
+
+// out = sum of n Jacobian points (n is the number of GPUs: a handful)
+__global__ void k_sum_jac(const G1Jac *__restrict__ pts, uint32_t n, G1Jac *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    G1Xyzz acc = xyzz_identity();
+    for (uint32_t i = 0; i < n; i++) acc = add_inline(acc, jac_to_xyzz(pts[i]));
     *out = xyzz_to_jac(acc);
 }
 
@@ -262,6 +342,13 @@ static void record(plonk_hip_ctx *ctx, int i) {
     if (ctx->profile) (void)hipEventRecord(ctx->ev[i], ctx->stream);
 }
 
+int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out) {
+    if (n == 0 || n > 0xffffffffull) return PLONK_HIP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_sum_jac, dim3(1), dim3(1), 0, ctx->stream, d_pts, (uint32_t)n, d_out);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
 int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out) {
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
@@ -288,6 +375,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz)));
     PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->big_list, ((size_t)nb + 1) * 4));
 
     uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
     uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
@@ -295,6 +383,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     G1Xyzz *buckets = (G1Xyzz *)ctx->buckets.ptr;
     G1Xyzz *part = (G1Xyzz *)ctx->seg_part.ptr;
     const G1Affine *table = (const G1Affine *)ctx->table.ptr;
+    uint32_t *big_count = (uint32_t *)ctx->big_list.ptr, *big_list = big_count + 1;
 
     record(ctx, PH_DIGITS);
     hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
@@ -307,7 +396,14 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
                        seg_len, table, buckets, part);
     record(ctx, PH_FIXUP);
-    hipLaunchKernelGGL(k_fixup, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, st, start, nb, seg_len, part, buckets);
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
+    // a typical bucket is cut into per_bucket / seg_len partials; only buckets well above
+    // that (skew) take the block-per-bucket path
+    const uint32_t serial_max = std::max<uint32_t>(16u, 2u * (uint32_t)std::ceil(per_bucket / seg_len) + 2u);
+    hipLaunchKernelGGL(k_fixup, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, st, start, nb, seg_len, part, buckets,
+                       serial_max, big_count, big_list);
+    hipLaunchKernelGGL(k_fixup_big, dim3(std::min<uint32_t>(nb, 1024u)), dim3(kSumBlock), 0, st, start, seg_len, part,
+                       buckets, big_count, big_list);
     record(ctx, PH_REDUCE);
 
     // ---- reduction levels
@@ -344,7 +440,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     }
     // ---- plain sums of every level's LW array
     size_t max_blocks_total = 0;
-    for (int l = 0; l < nlev; l++) max_blocks_total += cdiv(desc.n[l], 2 * kSumBlock);
+    for (int l = 0; l < nlev; l++) max_blocks_total += cdiv(desc.n[l], kSumPerBlock);
     PLONK_TRY(buf_reserve(ctx, ctx->red_sum_a, max_blocks_total * sizeof(G1Xyzz)));
     PLONK_TRY(buf_reserve(ctx, ctx->red_sum_b, max_blocks_total * sizeof(G1Xyzz)));
     const G1Xyzz *in = lw;
@@ -353,7 +449,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     while (true) {
         uint32_t max_n = 0, max_blocks = 0, off = 0;
         for (int l = 0; l < nlev; l++) {
-            uint32_t blocks = cdiv(desc.n[l], 2 * kSumBlock);
+            uint32_t blocks = cdiv(desc.n[l], kSumPerBlock);
             desc.out_off[l] = off;
             off += blocks;
             max_n = std::max(max_n, desc.n[l]);
@@ -363,7 +459,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
         hipLaunchKernelGGL(k_sum_pass, dim3(max_blocks, nlev), dim3(kSumBlock), 0, st, in, outs[flip], desc);
         for (int l = 0; l < nlev; l++) {
             desc.in_off[l] = desc.out_off[l];
-            desc.n[l] = cdiv(desc.n[l], 2 * kSumBlock);
+            desc.n[l] = cdiv(desc.n[l], kSumPerBlock);
         }
         in = outs[flip];
         flip ^= 1;

@@ -63,11 +63,11 @@ struct PowTable {
     Fr pw[32];  // tau^(2^k)
 };
 
-// out[i] = tau^i
-__global__ __launch_bounds__(256) void k_fr_powers(PowTable tab, size_t n, Fr *__restrict__ out) {
+// out[i] = first_power * tau^i
+__global__ __launch_bounds__(256) void k_fr_powers(PowTable tab, Fr first_power, size_t n, Fr *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr acc = fe_one<FrCfg>();
+    Fr acc = first_power;
     uint32_t e = (uint32_t)i;
 #pragma unroll 1
     for (int k = 0; k < 32; k++) {
@@ -189,21 +189,21 @@ int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
     return srs_build_levels(ctx, n);
 }
 
-int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts) {
-    if (!tau) return PLONK_HIP_ERR_INVALID_ARG;
-    size_t n = degree + 1;
+int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t n, uint64_t *out_pts) {
+    if (!tau || n == 0) return PLONK_HIP_ERR_INVALID_ARG;
     if (n >= 0xffffffffull) return PLONK_HIP_ERR_INVALID_ARG;
     PLONK_TRY(ensure_gen_table(ctx));
     PLONK_TRY(srs_begin(ctx, n));
     PowTable tab;
     memcpy(tab.pw[0].l, tau, sizeof(tab.pw[0].l));
     for (int k = 1; k < 32; k++) tab.pw[k] = fe_sqr(tab.pw[k - 1]);
+    Fr first_power = fe_pow_u64(tab.pw[0], (uint64_t)first);  // tau^first
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * sizeof(Fr)));
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_a, n * sizeof(G1Jac)));
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_b, n * sizeof(Fq)));
     Fr *pw = (Fr *)ctx->scratch_c.ptr;
     G1Jac *jac = (G1Jac *)ctx->scratch_a.ptr;
-    hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, tab, n, pw);
+    hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, tab, first_power, n, pw);
     hipLaunchKernelGGL(k_fixed_base, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, pw, n,
                        (const G1Affine *)ctx->gen_table.ptr, jac);
     if (out_pts) {

@@ -31,6 +31,8 @@ SIGNATURES = {
     "plonk_hip_srs_size": (ctypes.c_int, [c_ctx, c_sizep]),
     "plonk_hip_srs_read": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.c_size_t, c_u64p]),
     "plonk_hip_kzg_setup": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_kzg_setup_range": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_g1_sum_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_kzg_commit": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_kzg_commit_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_kzg_commit_batch": (
@@ -41,6 +43,7 @@ SIGNATURES = {
     "plonk_hip_profile": (ctypes.c_int, [c_ctx, ctypes.c_int]),
     "plonk_hip_msm_phase_ms": (ctypes.c_int, [c_ctx, c_floatp]),
     "plonk_hip_msm_phase_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "plonk_hip_bench_mad_rate": (ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_msm_plan": (ctypes.c_int, [c_ctx, c_intp, c_intp, c_sizep]),
     "plonk_hip_fr_ntt": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int]),
     "plonk_hip_fr_ntt_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int]),
