@@ -155,14 +155,10 @@ def main():
     be.profile(True)
     phases = []
 
+    from plonk_amd import sharding
+
     def step(record):
-        be.kzg_commit_dev(d_scalars, n_local, local_pt.data_ptr())
-        if world > 1:
-            be.sync()
-            dist.all_gather_into_tensor(gathered, local_pt)
-            torch.cuda.current_stream().synchronize()
-            if rank == 0:
-                be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
+        sharding.commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt)
         if record:
             phases.append(be.msm_phase_ms())  # waits for this step's MSM events
 

@@ -163,3 +163,28 @@ def test_commit_2_20_points_known_answer(backend):
     sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
     got = backend.kzg_commit(sc)
     assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+
+
+def test_commit_2_24_points_known_answer(backend):
+    # BASELINE config "2^24-point G1 MSM": size-independent known answer commit == [f(tau)]G
+    n = 1 << 24
+    tau = c.fr_to_mont([0x1234567 + (1 << 200)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    rng = np.random.default_rng(24)
+    sc = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    got = backend.kzg_commit(sc)
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+    # two half-range shards (SRS slices generated independently) sum to the same point
+    half = n // 2
+    d_out = backend.malloc(2 * 144)
+    parts = []
+    for r in range(2):
+        backend.kzg_setup_range(tau, r * half, half)
+        parts.append(backend.kzg_commit(sc[r * half:(r + 1) * half]))
+    d_parts = backend.to_device(np.stack(parts))
+    backend.g1_sum_dev(d_parts, 2, d_out)
+    backend.sync()
+    assert same_point(backend.from_device(d_out, (18,)), got)
+    backend.free(d_parts)
+    backend.free(d_out)

@@ -1,0 +1,62 @@
+"""world_size-2 rehearsal of the multi-GPU commitment on CPU (gloo): range split, all_gather of
+the partial points, combination on rank 0.  The per-rank MSM itself is stood in by the oracle
+here (no GPU in this suite); on GPUs the same protocol runs with plonk_hip_kzg_commit_dev."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import capi as c
+from oracle import pyref as o
+from plonk_amd import sharding
+
+
+def test_shard_ranges_partition_exactly():
+    for n, world in ((16, 1), (16, 2), (17, 4), (1 << 24, 8), (5, 8)):
+        spans = [sharding.shard_range(n, world, r) for r in range(world)]
+        assert spans[0][0] == 0
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+        assert spans[-1][0] + spans[-1][1] == n
+        assert max(cnt for _, cnt in spans) - min(cnt for _, cnt in spans) <= 1
+
+
+def _worker(rank, world, port, n, seed, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rnd = random.Random(seed)
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    srs = c.kzg_setup(tau, n - 1)
+    scalars = c.fr_to_mont([rnd.randrange(o.R) for _ in range(n)])
+    first, count = sharding.shard_range(n, world, rank)
+    partial = c.msm_naive(srs[first:first + count], scalars[first:first + count])
+    local = torch.from_numpy(partial.view(np.int64).copy())
+    gathered = sharding.gather_partials(local)
+    if rank == 0:
+        total = c.g1_identity()
+        for r in range(world):
+            total = c.g1_add(total, gathered[r].numpy().view(np.uint64))
+        full = c.msm_naive(srs, scalars)
+        ok = c.g1_compress(total.reshape(1, 18)) == c.g1_compress(full.reshape(1, 18))
+        kat = c.g1_compress(c.g1_mul(c.g1_generator(), c.fr_eval(scalars, tau)).reshape(1, 18))
+        with open(out_path, "w") as fh:
+            fh.write("ok" if ok and kat == c.g1_compress(total.reshape(1, 18)) else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 37), (3, 20)])
+def test_gathered_partials_sum_to_the_commitment(tmp_path, world, n):
+    c.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, port, n, 77, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
