@@ -132,6 +132,9 @@ const char *plonk_hip_msm_phase_name(int i);
 /* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
  * integer multiply-add `v_mad_u64_u32` issued from registers only; measured, takes ~50 ms. */
 int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
+/* Sustained Fq Montgomery multiplications per second (whole GPU) of dependent chains in
+ * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
+int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
 /* Window plan in force: bits per window, windows, buckets. */
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
 

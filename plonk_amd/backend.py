@@ -120,6 +120,11 @@ class Backend:
         self._check(self._lib.plonk_hip_bench_mad_rate(self._ctx, ctypes.byref(v)))
         return v.value
 
+    def bench_fq_mul_rate(self, variant=0, blocks_per_cu=8):
+        v = ctypes.c_double()
+        self._check(self._lib.plonk_hip_bench_fq_mul_rate(self._ctx, variant, blocks_per_cu, ctypes.byref(v)))
+        return v.value
+
     def msm_plan(self):
         c, w, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
         self._check(self._lib.plonk_hip_msm_plan(self._ctx, ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)))

@@ -76,7 +76,7 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
                       &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
-                      &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table};
+                      &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
         for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
@@ -246,6 +246,12 @@ int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {
     PLONK_TRY(bind(ctx));
     if (!mads_per_second) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_mad_rate(ctx, mads_per_second);
+}
+
+int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second) {
+    PLONK_TRY(bind(ctx));
+    if (!muls_per_second || blocks_per_cu < 1) return PLONK_HIP_ERR_INVALID_ARG;
+    return bench_fq_mul_rate(ctx, variant, blocks_per_cu, muls_per_second);
 }
 
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {

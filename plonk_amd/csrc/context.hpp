@@ -34,8 +34,8 @@ struct plonk_hip_ctx {
     std::string last_error;
     int window_bits_override = 0;
 
-    // SRS: `table` holds plan.nwin levels of srs_n affine points; level w, point i =
-    // [2^(c*w)] P_i at table[w * srs_n + i].
+    // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form
+    // (G1Affine28, 128 B each); level w, point i = [2^(c*w)] P_i at table[w * srs_n + i].
     size_t srs_n = 0;
     plonk::MsmPlan plan;
     plonk::DevBuf table;
@@ -46,6 +46,8 @@ struct plonk_hip_ctx {
     plonk::DevBuf scalars_stage, out_stage;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
+    // two levels of the SRS in 12 x 32-bit affine form while the window tables are being built
+    plonk::DevBuf level_a, level_b;
     // fixed-base table of the generator for kzg_setup (32 windows x 256 affine multiples)
     plonk::DevBuf gen_table;
     // twiddles for the NTT: per log_n forward and inverse tables
@@ -91,6 +93,7 @@ int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, 
 
 // microbench.hip
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
+int bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
 
 // srs.hip
 int srs_install_affine(plonk_hip_ctx *ctx, size_t n);  // level 0 already in ctx->table

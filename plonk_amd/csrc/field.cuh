@@ -177,11 +177,11 @@ PLONK_HD Fe<C> fe_dbl(const Fe<C> &a) {
     return r;
 }
 
-// Montgomery product a*b/R mod p: coarsely integrated operand scanning on 32-bit limbs.
-// Each step is one 32x32+64 multiply-add (v_mad_u64_u32).  Both moduli are below 2^(32N-1),
-// so the running value stays below 2p and N+1 limbs suffice ("no-carry" variant).
+// Montgomery product a*b/R mod p, portable form: coarsely integrated operand scanning on 32-bit
+// limbs.  Both moduli are below 2^(32N-1), so the running value stays below 2p and N+1 limbs
+// suffice ("no-carry" variant).
 template <class C>
-PLONK_HD Fe<C> fe_mul(const Fe<C> &a, const Fe<C> &b) {
+PLONK_HD Fe<C> fe_mul_cios(const Fe<C> &a, const Fe<C> &b) {
     constexpr int N = C::N;
     uint32_t t[N + 1];
 #pragma unroll
@@ -213,6 +213,11 @@ PLONK_HD Fe<C> fe_mul(const Fe<C> &a, const Fe<C> &b) {
     for (int i = 0; i < N; i++) r.l[i] = t[i];
     fe_reduce_once(r);
     return r;
+}
+
+template <class C>
+PLONK_HD Fe<C> fe_mul(const Fe<C> &a, const Fe<C> &b) {
+    return fe_mul_cios(a, b);
 }
 
 template <class C>

@@ -1,0 +1,105 @@
+// G1 bucket accumulation on the 28-bit limb form (field28.cuh): the group law of the MSM's hot
+// loop.  Same formulas and conventions as g1.cuh (XYZZ accumulators, affine identity = all
+// zero); only the field representation differs.  Window tables are stored in this form, one
+// 128-byte line per affine point.
+#pragma once
+#include "field28.cuh"
+#include "g1.cuh"
+
+namespace plonk {
+
+struct G1Affine28 {
+    Fq28 x, y;  // 2 x 64 B
+};
+struct G1Xyzz28 {
+    Fq28 x, y, zz, zzz;
+};
+
+PLONK_HD bool affine28_is_identity(const G1Affine28 &p) { return q28_is_zero(p.x) && q28_is_zero(p.y); }
+
+PLONK_HD G1Xyzz28 xyzz28_identity() {
+    G1Xyzz28 r;
+    r.x = q28_zero();
+    r.y = q28_zero();
+    r.zz = q28_zero();
+    r.zzz = q28_zero();
+    return r;
+}
+PLONK_HD bool xyzz28_is_identity(const G1Xyzz28 &p) { return q28_is_zero(p.zz); }
+
+// 2P for an affine P != identity (mdbl-2008-s-1).
+PLONK_HD G1Xyzz28 xyzz28_dbl_affine(const Fq28 &x, const Fq28 &y) {
+    Fq28 U = q28_dbl(y);
+    Fq28 V = q28_mul(U, U);
+    Fq28 W = q28_mul(U, V);
+    Fq28 S = q28_mul(x, V);
+    Fq28 XX = q28_mul(x, x);
+    Fq28 M = q28_add(q28_dbl(XX), XX);
+    G1Xyzz28 r;
+    r.x = q28_sub(q28_sub(q28_mul(M, M), S), S);
+    r.y = q28_sub(q28_mul(M, q28_sub(S, r.x)), q28_mul(W, y));
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+
+// acc += (x2, y2) for an affine point that is not the identity (madd-2008-s: 8M + 2S), except
+// when (x2, y2) equals acc: then acc is left alone and false is returned -- the caller doubles.
+PLONK_HD bool xyzz28_madd_nodbl(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2) {
+    if (xyzz28_is_identity(acc)) {
+        acc.x = x2;
+        acc.y = y2;
+        acc.zz = q28_one();
+        acc.zzz = q28_one();
+        return true;
+    }
+    Fq28 U2 = q28_mul(x2, acc.zz);
+    Fq28 S2 = q28_mul(y2, acc.zzz);
+    Fq28 P = q28_sub(U2, acc.x);
+    Fq28 R = q28_sub(S2, acc.y);
+    if (q28_is_zero(P)) {
+        if (q28_is_zero(R)) return false;
+        acc = xyzz28_identity();
+        return true;
+    }
+    Fq28 PP = q28_mul(P, P);
+    Fq28 PPP = q28_mul(P, PP);
+    Fq28 Q = q28_mul(acc.x, PP);
+    Fq28 X3 = q28_sub(q28_sub(q28_sub(q28_mul(R, R), PPP), Q), Q);
+    Fq28 Y3 = q28_sub(q28_mul(R, q28_sub(Q, X3)), q28_mul(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = q28_mul(acc.zz, PP);
+    acc.zzz = q28_mul(acc.zzz, PPP);
+    return true;
+}
+
+PLONK_HD void xyzz28_madd(G1Xyzz28 &acc, const G1Affine28 &p, bool negate) {
+    if (affine28_is_identity(p)) return;
+    Fq28 y = negate ? q28_neg(p.y) : p.y;
+    if (!xyzz28_madd_nodbl(acc, p.x, y)) acc = xyzz28_dbl_affine(p.x, y);
+}
+
+// representation changes (the rest of the pipeline works on the 12 x 32-bit form)
+PLONK_HD G1Affine28 affine28_from(const G1Affine &p) {
+    G1Affine28 r;
+    r.x = q28_from_fq(p.x);  // 0 -> 0, so the all-zero identity code is preserved
+    r.y = q28_from_fq(p.y);
+    return r;
+}
+PLONK_HD G1Affine affine28_to(const G1Affine28 &p) {
+    G1Affine r;
+    r.x = q28_to_fq(p.x);
+    r.y = q28_to_fq(p.y);
+    return r;
+}
+PLONK_HD G1Xyzz xyzz28_to(const G1Xyzz28 &p) {
+    G1Xyzz r;
+    r.x = q28_to_fq(p.x);
+    r.y = q28_to_fq(p.y);
+    r.zz = q28_to_fq(p.zz);
+    r.zzz = q28_to_fq(p.zzz);
+    return r;
+}
+
+}  // namespace plonk

@@ -1,6 +1,7 @@
 // Peak-rate probes for the roofline: the integer VALU multiply-add that every field
 // multiplication is made of (v_mad_u64_u32), issued from registers only.
 #include "context.hpp"
+#include "field28.cuh"
 
 namespace plonk {
 
@@ -23,6 +24,89 @@ __global__ __launch_bounds__(256) void k_mad_rate(uint32_t *__restrict__ out, ui
 #pragma unroll
     for (int j = 0; j < 8; j++) s ^= acc[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+
+// Field multiplication throughput: every lane runs a dependent chain x <- x*y, y <- y*x.
+// variant 0: device form (fe_mul), 1: portable CIOS form.
+// 28-bit limb form: variant 2 = q28_mul, 3 = q28_sqr + q28_mul
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_q28_mul_rate(uint32_t *__restrict__ out, uint32_t seed, int iters) {
+    Fq28 x, y;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        x.l[i] = (seed + threadIdx.x * 977u + i * 131u) & 0x00ffffffu;
+        y.l[i] = (seed ^ (blockIdx.x * 613u + i * 257u)) & 0x00ffffffu;
+    }
+    for (int i = 0; i < iters; i++) {
+        if (VARIANT == 2) {
+            x = q28_mul(x, y);
+            y = q28_mul(y, x);
+        } else {
+            x = q28_sqr(y);
+            y = q28_mul(y, x);
+        }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) s ^= x.l[i] ^ y.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_fq_mul_rate(uint32_t *__restrict__ out, uint32_t seed, int iters) {
+    Fq x, y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        x.l[i] = (seed + threadIdx.x * 977u + i * 131u) & 0x0fffffffu;
+        y.l[i] = (seed ^ (blockIdx.x * 613u + i * 257u)) & 0x0fffffffu;
+    }
+    for (int i = 0; i < iters; i++) {
+        if (VARIANT == 0) {
+            x = fe_mul(x, y);
+            y = fe_mul(y, x);
+        } else {
+            x = fe_mul_cios(x, y);
+            y = fe_mul_cios(y, x);
+        }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) s ^= x.l[i] ^ y.l[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second) {
+    const int blocks = 256 * blocks_per_cu, threads = 256, iters = 512;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4));
+    hipEvent_t e0, e1;
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e0));
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        PLONK_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        if (variant == 2) {
+            hipLaunchKernelGGL(k_q28_mul_rate<2>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (uint32_t *)ctx->scratch_c.ptr, 0x1234567u + rep, iters);
+        } else if (variant == 3) {
+            hipLaunchKernelGGL(k_q28_mul_rate<3>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (uint32_t *)ctx->scratch_c.ptr, 0x1234567u + rep, iters);
+        } else if (variant == 0) {
+            hipLaunchKernelGGL(k_fq_mul_rate<0>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (uint32_t *)ctx->scratch_c.ptr, 0x1234567u + rep, iters);
+        } else {
+            hipLaunchKernelGGL(k_fq_mul_rate<1>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (uint32_t *)ctx->scratch_c.ptr, 0x1234567u + rep, iters);
+        }
+        PLONK_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *muls_per_second = (double)blocks * threads * (double)iters * 2.0 / (best * 1e-3);
+    return PLONK_HIP_OK;
 }
 
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {

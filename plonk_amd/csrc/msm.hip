@@ -10,7 +10,8 @@
 //   2. sort_pairs    radix sort of the n*nwin pairs by bucket
 //   3. k_bounds      first sorted position of every bucket
 //   4. k_accumulate  one lane per fixed-length SEGMENT of the sorted list: gathers the affine
-//                    table points and adds them into an XYZZ accumulator (8M + 2S per point).
+//                    table points (one 128-byte line each) and adds them into an XYZZ
+//                    accumulator (8M + 2S per point) on 28-bit limbs (field28.cuh).
 //                    Buckets lying wholly inside a segment are written directly; runs cut by a
 //                    segment border are written as partials.  Work per lane is uniform whatever
 //                    the scalar distribution.
@@ -22,6 +23,7 @@
 #include <cmath>
 
 #include "context.hpp"
+#include "g1_28.cuh"
 #include "msm_core.cuh"
 
 namespace plonk {
@@ -34,7 +36,14 @@ static constexpr int kSumBlock = 256;
 
 // Out-of-line group operations: one copy of each per code object.  The doubling cases are rare
 // (equal operands).
-__device__ __noinline__ void dbl_affine_cold(G1Xyzz &acc, const Fq &x, const Fq &y) { acc = xyzz_dbl_affine(x, y); }
+// 2 * (+-table[v]) for a table entry that is not the identity.  Takes the entry by index and
+// returns by value, so that no caller variable has its address taken (an address-taken
+// accumulator would live in scratch memory for the whole loop).
+__device__ __noinline__ G1Xyzz28 dbl_entry_cold(const G1Affine28 *__restrict__ table, uint32_t v) {
+    G1Affine28 pt = table[v & 0x7fffffffu];
+    Fq28 y = (v >> 31) ? q28_neg(pt.y) : pt.y;
+    return xyzz28_dbl_affine(pt.x, y);
+}
 __device__ __noinline__ void dbl_cold(G1Xyzz &out, const G1Xyzz &a) { out = xyzz_dbl(a); }
 
 // ------------------------------------------------------------------------------------------
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(256) void k_bounds(const uint32_t *__restrict__ key
 __device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint32_t run_end, uint32_t seg_begin,
                                           size_t seg, const uint32_t *__restrict__ start,
                                           G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part,
-                                          const G1Xyzz &acc) {
+                                          const G1Xyzz28 &acc28) {
+    const G1Xyzz acc = xyzz28_to(acc28);  // the tail kernels work on the 12 x 32-bit form
     if (start[key] == run_begin && start[key + 1] == run_end) {
         buckets[key] = acc;  // the whole bucket lies inside this segment
     } else if (run_begin == seg_begin) {
@@ -94,7 +104,7 @@ __device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint
 __global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
-                                                       uint32_t seg_len, const G1Affine *__restrict__ table,
+                                                       uint32_t seg_len, const G1Affine28 *__restrict__ table,
                                                        G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part) {
     size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nvalid = start[nbuckets];
@@ -104,23 +114,36 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restric
     size_t end64 = begin64 + seg_len;
     uint32_t end = end64 < nvalid ? (uint32_t)end64 : nvalid;
 
-    uint32_t cur = keys[begin];
+    uint32_t k = keys[begin], v = vals[begin];
+    uint32_t cur = k;
     uint32_t run_begin = begin;
-    G1Xyzz acc = xyzz_identity();
+    G1Xyzz28 acc = xyzz28_identity();
     for (uint32_t p = begin; p < end; p++) {
-        uint32_t k = keys[p];
+        // (bucket, entry) of the next position, fetched one iteration ahead
+        const bool more = p + 1 < end;
+        uint32_t kn = 0, vn = 0;
+        if (more) {
+            kn = keys[p + 1];
+            vn = vals[p + 1];
+        }
         if (k != cur) {
             flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
             cur = k;
             run_begin = p;
-            acc = xyzz_identity();
+            acc = xyzz28_identity();
         }
-        uint32_t v = vals[p];
-        G1Affine pt = table[v & 0x7fffffffu];
-        if (!affine_is_identity(pt)) {
-            Fq y = (v >> 31) ? fe_neg(pt.y) : pt.y;
-            if (!xyzz_madd_nodbl(acc, pt.x, y)) dbl_affine_cold(acc, pt.x, y);
+        G1Affine28 pt = table[v & 0x7fffffffu];
+        // Pull the next point's 128-byte line towards the L2 while this addition runs: one
+        // dword read whose value is only consumed (by an empty asm) after the addition.
+        uint32_t touch = 0;
+        if (more) touch = table[vn & 0x7fffffffu].x.l[0];
+        if (!affine28_is_identity(pt)) {
+            Fq28 y = (v >> 31) ? q28_neg(pt.y) : pt.y;
+            if (!xyzz28_madd_nodbl(acc, pt.x, y)) acc = dbl_entry_cold(table, v);
         }
+        asm volatile("" ::"v"(touch));
+        k = kn;
+        v = vn;
     }
     flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
 }
@@ -382,7 +405,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     uint32_t *start = (uint32_t *)ctx->bucket_start.ptr;
     G1Xyzz *buckets = (G1Xyzz *)ctx->buckets.ptr;
     G1Xyzz *part = (G1Xyzz *)ctx->seg_part.ptr;
-    const G1Affine *table = (const G1Affine *)ctx->table.ptr;
+    const G1Affine28 *table = (const G1Affine28 *)ctx->table.ptr;
     uint32_t *big_count = (uint32_t *)ctx->big_list.ptr, *big_list = big_count + 1;
 
     record(ctx, PH_DIGITS);

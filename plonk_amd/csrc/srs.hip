@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include "g1_28.cuh"
 #include "msm_core.cuh"
 
 namespace plonk {
@@ -57,6 +58,15 @@ __global__ __launch_bounds__(128) void k_window_shift(const G1Affine *__restrict
         for (int k = 0; k < c; k++) p = jac_dbl(p);
     }
     next[i] = p;
+}
+
+// One level of the resident window table: 12 x 32-bit affine points -> the 28-bit limb form the
+// accumulation kernel reads (one 128-byte line per point).
+__global__ __launch_bounds__(256) void k_to_table28(const G1Affine *__restrict__ in, G1Affine28 *__restrict__ out,
+                                                   size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = affine28_from(in[i]);
 }
 
 struct PowTable {
@@ -153,24 +163,33 @@ static int srs_begin(plonk_hip_ctx *ctx, size_t n) {
     MsmPlan pl = msm_choose_plan(n, ctx->window_bits_override);
     if ((double)n * pl.nwin >= 2147483648.0) return PLONK_HIP_ERR_INVALID_ARG;
     ctx->srs_n = 0;
-    PLONK_TRY(buf_reserve(ctx, ctx->table, n * (size_t)pl.nwin * sizeof(G1Affine)));
+    PLONK_TRY(buf_reserve(ctx, ctx->table, n * (size_t)pl.nwin * sizeof(G1Affine28)));
+    PLONK_TRY(buf_reserve(ctx, ctx->level_a, n * sizeof(G1Affine)));
+    PLONK_TRY(buf_reserve(ctx, ctx->level_b, n * sizeof(G1Affine)));
     ctx->plan = pl;
     return PLONK_HIP_OK;
 }
 
-// Levels 1..nwin-1 from level 0: c doublings per level, then shared-inversion normalisation.
+// Level 0 (12 x 32-bit affine, in ctx->level_a) -> every level of the 28-bit table: c doublings
+// per level, shared-inversion normalisation, conversion.
 static int srs_build_levels(plonk_hip_ctx *ctx, size_t n) {
     const MsmPlan &pl = ctx->plan;
-    G1Affine *table = (G1Affine *)ctx->table.ptr;
+    G1Affine28 *table = (G1Affine28 *)ctx->table.ptr;
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_a, n * sizeof(G1Jac)));
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_b, n * sizeof(Fq)));
     G1Jac *jac = (G1Jac *)ctx->scratch_a.ptr;
     Fq *scr = (Fq *)ctx->scratch_b.ptr;
+    G1Affine *prev = (G1Affine *)ctx->level_a.ptr, *next = (G1Affine *)ctx->level_b.ptr;
+    hipLaunchKernelGGL(k_to_table28, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, prev, table, n);
     for (int w = 1; w < pl.nwin; w++) {
-        hipLaunchKernelGGL(k_window_shift, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, table + (size_t)(w - 1) * n,
-                           jac, n, pl.c);
-        hipLaunchKernelGGL(k_batch_to_affine, dim3(cdiv(cdiv(n, kBatch), 128)), dim3(128), 0, ctx->stream, jac,
-                           table + (size_t)w * n, n, scr);
+        hipLaunchKernelGGL(k_window_shift, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, prev, jac, n, pl.c);
+        hipLaunchKernelGGL(k_batch_to_affine, dim3(cdiv(cdiv(n, kBatch), 128)), dim3(128), 0, ctx->stream, jac, next,
+                           n, scr);
+        hipLaunchKernelGGL(k_to_table28, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, next, table + (size_t)w * n,
+                           n);
+        G1Affine *t = prev;
+        prev = next;
+        next = t;
     }
     PLONK_HIP_TRY(ctx, hipGetLastError());
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -185,7 +204,7 @@ int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_b, n * sizeof(Fq)));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.ptr, pts, n * sizeof(G1Jac), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_batch_to_affine, dim3(cdiv(cdiv(n, kBatch), 128)), dim3(128), 0, ctx->stream,
-                       (const G1Jac *)ctx->scratch_a.ptr, (G1Affine *)ctx->table.ptr, n, (Fq *)ctx->scratch_b.ptr);
+                       (const G1Jac *)ctx->scratch_a.ptr, (G1Affine *)ctx->level_a.ptr, n, (Fq *)ctx->scratch_b.ptr);
     return srs_build_levels(ctx, n);
 }
 
@@ -210,15 +229,15 @@ int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t n,
         PLONK_HIP_TRY(ctx, hipMemcpyAsync(out_pts, jac, n * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
     }
     hipLaunchKernelGGL(k_batch_to_affine, dim3(cdiv(cdiv(n, kBatch), 128)), dim3(128), 0, ctx->stream, jac,
-                       (G1Affine *)ctx->table.ptr, n, (Fq *)ctx->scratch_b.ptr);
+                       (G1Affine *)ctx->level_a.ptr, n, (Fq *)ctx->scratch_b.ptr);
     return srs_build_levels(ctx, n);
 }
 
 // affine table entries -> Jacobian triples with Z = 1 (identity -> (1, 1, 0))
-__global__ void k_affine_to_jac(const G1Affine *__restrict__ in, G1Jac *__restrict__ out, size_t n) {
+__global__ void k_affine_to_jac(const G1Affine28 *__restrict__ in, G1Jac *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Affine a = in[i];
+    G1Affine a = affine28_to(in[i]);
     G1Jac p;
     if (affine_is_identity(a)) {
         p = jac_identity();
@@ -236,7 +255,7 @@ int srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out) {
     if (count == 0) return PLONK_HIP_OK;
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_a, count * sizeof(G1Jac)));
     hipLaunchKernelGGL(k_affine_to_jac, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream,
-                       (const G1Affine *)ctx->table.ptr + first, (G1Jac *)ctx->scratch_a.ptr, count);
+                       (const G1Affine28 *)ctx->table.ptr + first, (G1Jac *)ctx->scratch_a.ptr, count);
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch_a.ptr, count * sizeof(G1Jac), hipMemcpyDeviceToHost,
                                       ctx->stream));
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../plonk_amd/csrc/g1.cuh"
+#include "../../plonk_amd/csrc/g1_28.cuh"
 #include "../../plonk_amd/csrc/msm_core.cuh"
 
 using namespace plonk;
@@ -100,3 +101,45 @@ extern "C" void hc_scalar_digits(const uint32_t *scalar_mont, int c, int nwin, i
     for (int w = 0; w < nwin; w++) out[w] = signed_digit(k, w, c, carry);
 }
 extern "C" int hc_num_windows(int c) { return msm_num_windows(c); }
+
+// 28-bit limb form: operands and results cross this boundary in the 12 x 32-bit Montgomery form
+// (converted in and out with the header's own converters).
+#define VEC2_28(name, fn)                                                                 \
+    extern "C" void name(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n) { \
+        for (size_t i = 0; i < n; i++)                                                    \
+            st<FqCfg>(out + 12 * i, q28_to_fq(fn(q28_from_fq(ld<FqCfg>(a + 12 * i)),      \
+                                                 q28_from_fq(ld<FqCfg>(b + 12 * i)))));   \
+    }
+VEC2_28(hc_q28_mul, q28_mul)
+VEC2_28(hc_q28_add, q28_add)
+VEC2_28(hc_q28_sub, q28_sub)
+extern "C" void hc_q28_sqr(const uint32_t *a, uint32_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) st<FqCfg>(out + 12 * i, q28_to_fq(q28_sqr(q28_from_fq(ld<FqCfg>(a + 12 * i)))));
+}
+extern "C" void hc_q28_roundtrip(const uint32_t *a, uint32_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) st<FqCfg>(out + 12 * i, q28_to_fq(q28_from_fq(ld<FqCfg>(a + 12 * i))));
+}
+// raw limbs of the converted value (14 words), to check canonical form
+extern "C" void hc_q28_limbs(const uint32_t *a, uint32_t *out14, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        Fq28 v = q28_from_fq(ld<FqCfg>(a + 12 * i));
+        memcpy(out14 + 14 * i, v.l, 56);
+    }
+}
+
+// Mixed addition on the 28-bit limb form.  acc_in/out: XYZZ in the 12 x 32-bit form (the
+// accumulator is re-created in 28-bit form from affine points by the caller's sequence);
+// here: fold a list of n affine points (with signs) into one accumulator and convert back.
+extern "C" void hc_xyzz28_fold(const uint32_t *aff, const int *negate, size_t n, uint32_t *out_xyzz) {
+    G1Xyzz28 acc = xyzz28_identity();
+    for (size_t i = 0; i < n; i++) {
+        G1Affine28 p = affine28_from(lda(aff + 24 * i));
+        xyzz28_madd(acc, p, negate[i] != 0);
+    }
+    G1Xyzz r = xyzz28_to(acc);
+    memcpy(out_xyzz, &r, sizeof(r));
+}
+extern "C" void hc_affine28_roundtrip(const uint32_t *aff, uint32_t *out) {
+    G1Affine r = affine28_to(affine28_from(lda(aff)));
+    memcpy(out, &r, sizeof(r));
+}

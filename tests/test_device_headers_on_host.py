@@ -143,3 +143,54 @@ def test_signed_digits_recompose(hc, cbits):
         hc.hc_scalar_digits(_p32(sm), cbits, nwin, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
         assert all(-half < int(d) <= half for d in out)
         assert sum(int(d) << (cbits * w) for w, d in enumerate(out)) == v
+
+
+def test_28_bit_limb_form_matches_fq(hc):
+    rnd = random.Random(31)
+    a = [rnd.randrange(o.Q) for _ in range(300)] + [0, 1, o.Q - 1, o.Q - 1, 0, 2, o.Q - 2]
+    b = [rnd.randrange(o.Q) for _ in range(300)] + [o.Q - 1, 0, o.Q - 1, 1, 0, o.Q - 2, o.Q - 1]
+    A, B = c.fq_to_mont(a), c.fq_to_mont(b)
+    assert np.array_equal(_vec1(hc.hc_q28_roundtrip, A), A)
+    assert c.fq_from_mont(_vec2(hc.hc_q28_mul, A, B)) == [x * y % o.Q for x, y in zip(a, b)]
+    assert c.fq_from_mont(_vec2(hc.hc_q28_add, A, B)) == [(x + y) % o.Q for x, y in zip(a, b)]
+    assert c.fq_from_mont(_vec2(hc.hc_q28_sub, A, B)) == [(x - y) % o.Q for x, y in zip(a, b)]
+    assert c.fq_from_mont(_vec1(hc.hc_q28_sqr, A)) == [x * x % o.Q for x in a]
+    # canonical limbs: value * 2^392 mod q sliced into 28-bit limbs
+    limbs = np.zeros((len(a), 14), dtype=np.uint32)
+    hc.hc_q28_limbs(_p32(np.ascontiguousarray(A)), limbs.ctypes.data_as(u32p), ctypes.c_size_t(len(a)))
+    for x, row in zip(a, limbs):
+        want = x * pow(2, 392, o.Q) % o.Q
+        assert [int(v) for v in row] == [(want >> (28 * i)) & 0xFFFFFFF for i in range(14)]
+
+
+def test_28_bit_bucket_accumulation(hc):
+    rnd = random.Random(32)
+    g = c.g1_generator()
+    pts = [c.g1_mul(g, c.fr_to_mont([rnd.randrange(1, o.R)])[0]) for _ in range(5)]
+    ref = c.g1_from_limbs(np.stack(pts))
+    aff = c.g1_to_affine(np.stack(pts))
+    ident_aff = np.zeros(12, dtype=np.uint64)
+
+    def fold(seq):
+        a = np.ascontiguousarray(np.stack([x for x, _ in seq]))
+        neg = (ctypes.c_int * len(seq))(*[int(s) for _, s in seq])
+        out = np.empty(24, dtype=np.uint64)
+        hc.hc_xyzz28_fold(_p32(a), neg, ctypes.c_size_t(len(seq)), _p32(out))
+        return _xyzz_to_point(hc, out)
+
+    rt = np.empty(12, dtype=np.uint64)
+    hc.hc_affine28_roundtrip(_p32(np.ascontiguousarray(aff[0])), _p32(rt))
+    assert np.array_equal(rt, aff[0])
+    assert o.g1_eq(fold([(aff[0], 0)]), ref[0])
+    assert o.g1_eq(fold([(aff[0], 0), (aff[1], 0), (aff[2], 1)]), o.g1_sub(o.g1_add(ref[0], ref[1]), ref[2]))
+    assert o.g1_eq(fold([(aff[3], 0), (aff[3], 0)]), o.g1_double(ref[3]))          # doubling branch
+    assert o.g1_is_identity(fold([(aff[3], 0), (aff[3], 1)]))                      # P - P
+    assert o.g1_eq(fold([(aff[3], 0), (aff[3], 1), (aff[4], 1)]), o.g1_neg(ref[4]))  # restart from identity
+    assert o.g1_eq(fold([(ident_aff, 0), (aff[1], 0), (ident_aff, 1)]), ref[1])    # identity operands
+    want = o.G1_IDENTITY
+    seq = []
+    for i in range(40):
+        j, sgn = rnd.randrange(5), rnd.randrange(2)
+        seq.append((aff[j], sgn))
+        want = o.g1_add(want, o.g1_neg(ref[j]) if sgn else ref[j])
+    assert o.g1_eq(fold(seq), want)
