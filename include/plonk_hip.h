@@ -132,6 +132,10 @@ const char *plonk_hip_msm_phase_name(int i);
 /* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
  * integer multiply-add `v_mad_u64_u32` issued from registers only; measured, takes ~50 ms. */
 int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
+/* Issue-cost probe: multiply-add rate with `extra` (0, 1, 2 or 4) cheap integer VALU instructions
+ * after every multiply-add, and the shader clock (GHz) the kernel ran at. */
+int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second,
+                             double *clock_ghz);
 /* Sustained Fq Montgomery multiplications per second (whole GPU) of dependent chains in
  * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
 int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);

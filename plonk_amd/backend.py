@@ -120,6 +120,12 @@ class Backend:
         self._check(self._lib.plonk_hip_bench_mad_rate(self._ctx, ctypes.byref(v)))
         return v.value
 
+    def bench_mad_mix(self, extra=0, blocks_per_cu=8):
+        v, clk = ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.plonk_hip_bench_mad_mix(self._ctx, extra, blocks_per_cu, ctypes.byref(v),
+                                                      ctypes.byref(clk)))
+        return v.value, clk.value
+
     def bench_fq_mul_rate(self, variant=0, blocks_per_cu=8):
         v = ctypes.c_double()
         self._check(self._lib.plonk_hip_bench_fq_mul_rate(self._ctx, variant, blocks_per_cu, ctypes.byref(v)))

@@ -254,6 +254,13 @@ int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_
     return bench_fq_mul_rate(ctx, variant, blocks_per_cu, muls_per_second);
 }
 
+int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second,
+                             double *clock_ghz) {
+    PLONK_TRY(bind(ctx));
+    if (!mads_per_second || !clock_ghz || blocks_per_cu < 1) return PLONK_HIP_ERR_INVALID_ARG;
+    return bench_mad_mix(ctx, extra, blocks_per_cu, mads_per_second, clock_ghz);
+}
+
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {
     if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
     ctx->profile = enable != 0;

@@ -43,8 +43,18 @@ PLONK_HD G1Xyzz28 xyzz28_dbl_affine(const Fq28 &x, const Fq28 &y) {
     return r;
 }
 
+// Keeps the instruction scheduler from interleaving two steps of the addition: every step is a
+// 392-multiply-add field product, so nothing is gained by overlapping them, while overlapping
+// lengthens live ranges past the 168 registers that three waves per SIMD allow.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PLONK_STEP() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PLONK_STEP() ((void)0)
+#endif
+
 // acc += (x2, y2) for an affine point that is not the identity (madd-2008-s: 8M + 2S), except
 // when (x2, y2) equals acc: then acc is left alone and false is returned -- the caller doubles.
+// The steps are ordered so that at most eight field elements are live at any time.
 PLONK_HD bool xyzz28_madd_nodbl(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2) {
     if (xyzz28_is_identity(acc)) {
         acc.x = x2;
@@ -53,25 +63,86 @@ PLONK_HD bool xyzz28_madd_nodbl(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2) {
         acc.zzz = q28_one();
         return true;
     }
-    Fq28 U2 = q28_mul(x2, acc.zz);
-    Fq28 S2 = q28_mul(y2, acc.zzz);
-    Fq28 P = q28_sub(U2, acc.x);
-    Fq28 R = q28_sub(S2, acc.y);
+    Fq28 P = q28_sub(q28_mul(x2, acc.zz), acc.x);  // U2 - X1
+    PLONK_STEP();
+    Fq28 R = q28_sub(q28_mul(y2, acc.zzz), acc.y);  // S2 - Y1
+    PLONK_STEP();
     if (q28_is_zero(P)) {
         if (q28_is_zero(R)) return false;
         acc = xyzz28_identity();
         return true;
     }
     Fq28 PP = q28_mul(P, P);
-    Fq28 PPP = q28_mul(P, PP);
-    Fq28 Q = q28_mul(acc.x, PP);
-    Fq28 X3 = q28_sub(q28_sub(q28_sub(q28_mul(R, R), PPP), Q), Q);
-    Fq28 Y3 = q28_sub(q28_mul(R, q28_sub(Q, X3)), q28_mul(acc.y, PPP));
-    acc.x = X3;
-    acc.y = Y3;
+    PLONK_STEP();
     acc.zz = q28_mul(acc.zz, PP);
+    PLONK_STEP();
+    Fq28 PPP = q28_mul(P, PP);
+    PLONK_STEP();
     acc.zzz = q28_mul(acc.zzz, PPP);
+    PLONK_STEP();
+    Fq28 Q = q28_mul(acc.x, PP);
+    PLONK_STEP();
+    Fq28 T = q28_mul(acc.y, PPP);
+    PLONK_STEP();
+    acc.x = q28_sub(q28_sub(q28_sub(q28_mul(R, R), PPP), Q), Q);
+    PLONK_STEP();
+    acc.y = q28_sub(q28_mul(R, q28_sub(Q, acc.x)), T);
     return true;
+}
+
+// 2P, general ZZ (dbl-2008-s-1, a = 0).
+PLONK_HD G1Xyzz28 xyzz28_dbl(const G1Xyzz28 &p) {
+    if (xyzz28_is_identity(p)) return xyzz28_identity();
+    Fq28 U = q28_dbl(p.y);
+    Fq28 V = q28_mul(U, U);
+    Fq28 W = q28_mul(U, V);
+    Fq28 S = q28_mul(p.x, V);
+    Fq28 XX = q28_mul(p.x, p.x);
+    Fq28 M = q28_add(q28_dbl(XX), XX);
+    G1Xyzz28 r;
+    r.x = q28_sub(q28_sub(q28_mul(M, M), S), S);
+    r.y = q28_sub(q28_mul(M, q28_sub(S, r.x)), q28_mul(W, p.y));
+    r.zz = q28_mul(V, p.zz);
+    r.zzz = q28_mul(W, p.zzz);
+    return r;
+}
+
+// out = a + b, both XYZZ (add-2008-s: 12M + 2S), except when a == b (both non-identity):
+// returns false and leaves out untouched -- the caller doubles.
+PLONK_HD bool xyzz28_add_nodbl(G1Xyzz28 &out, const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    if (xyzz28_is_identity(a)) {
+        out = b;
+        return true;
+    }
+    if (xyzz28_is_identity(b)) {
+        out = a;
+        return true;
+    }
+    Fq28 U1 = q28_mul(a.x, b.zz);
+    Fq28 P = q28_sub(q28_mul(b.x, a.zz), U1);
+    Fq28 S1 = q28_mul(a.y, b.zzz);
+    Fq28 R = q28_sub(q28_mul(b.y, a.zzz), S1);
+    if (q28_is_zero(P)) {
+        if (q28_is_zero(R)) return false;
+        out = xyzz28_identity();
+        return true;
+    }
+    Fq28 PP = q28_mul(P, P);
+    Fq28 PPP = q28_mul(P, PP);
+    Fq28 Q = q28_mul(U1, PP);
+    G1Xyzz28 r;
+    r.x = q28_sub(q28_sub(q28_sub(q28_mul(R, R), PPP), Q), Q);
+    r.y = q28_sub(q28_mul(R, q28_sub(Q, r.x)), q28_mul(S1, PPP));
+    r.zz = q28_mul(q28_mul(a.zz, b.zz), PP);
+    r.zzz = q28_mul(q28_mul(a.zzz, b.zzz), PPP);
+    out = r;
+    return true;
+}
+
+PLONK_HD G1Xyzz28 xyzz28_add(const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    G1Xyzz28 r;
+    if (!xyzz28_add_nodbl(r, a, b)) r = xyzz28_dbl(a);
+    return r;
 }
 
 PLONK_HD void xyzz28_madd(G1Xyzz28 &acc, const G1Affine28 &p, bool negate) {

@@ -109,6 +109,74 @@ int bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double
     return PLONK_HIP_OK;
 }
 
+// Issue-cost probe: EXTRA cheap integer VALU instructions after every multiply-add, 8 independent
+// chains per lane.  Reports multiply-adds per second and the shader clock seen by the kernel.
+template <int EXTRA>
+__global__ __launch_bounds__(256) void k_mad_mix(uint32_t *__restrict__ out, uint64_t *__restrict__ clocks,
+                                                 uint32_t seed, int iters) {
+    uint32_t a = seed ^ (threadIdx.x * 2654435761u), b = seed + blockIdx.x * 40503u + 12345u;
+    uint64_t acc[8];
+    uint32_t x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        acc[j] = (uint64_t)(a + j) << 7;
+        x[j] = a * (j + 3);
+    }
+    uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b) : "vcc");
+#pragma unroll
+                for (int e = 0; e < EXTRA; e++) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(x[j]) : "v"(b));
+            }
+        }
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s ^= acc[j] ^ x[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        clocks[0] = t1 - t0;
+        clocks[1] = r1 - r0;
+    }
+}
+
+int bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second, double *clock_ghz) {
+    const int blocks = 256 * blocks_per_cu, threads = 256, iters = 2048;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4 + 64));
+    uint32_t *out = (uint32_t *)ctx->scratch_c.ptr;
+    uint64_t *clk = (uint64_t *)((char *)ctx->scratch_c.ptr + (size_t)blocks * threads * 4);
+    hipEvent_t e0, e1;
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e0));
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        PLONK_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        switch (extra) {
+            case 0: hipLaunchKernelGGL(k_mad_mix<0>, dim3(blocks), dim3(threads), 0, ctx->stream, out, clk, 7u + rep, iters); break;
+            case 1: hipLaunchKernelGGL(k_mad_mix<1>, dim3(blocks), dim3(threads), 0, ctx->stream, out, clk, 7u + rep, iters); break;
+            case 2: hipLaunchKernelGGL(k_mad_mix<2>, dim3(blocks), dim3(threads), 0, ctx->stream, out, clk, 7u + rep, iters); break;
+            default: hipLaunchKernelGGL(k_mad_mix<4>, dim3(blocks), dim3(threads), 0, ctx->stream, out, clk, 7u + rep, iters); break;
+        }
+        PLONK_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    uint64_t h[2];
+    PLONK_HIP_TRY(ctx, hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+    *mads_per_second = (double)blocks * threads * (double)iters * 32.0 / (best * 1e-3);
+    *clock_ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;  // s_memrealtime ticks at 100 MHz
+    return PLONK_HIP_OK;
+}
+
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {
     const int blocks = 256 * 8, threads = 256, iters = 4096;
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4));

@@ -32,19 +32,18 @@ static constexpr int kBlock = 128;
 static constexpr int kChunk = 4;       // bucket-reduction chunk (the "4" in the Horner step)
 static constexpr int kChunkLog = 2;
 static constexpr int kMaxLevels = 16;  // 2^(c-1) buckets, c <= 24 -> 12 levels
-static constexpr int kSumBlock = 256;
+static constexpr int kSumBlock = 128;
 
-// Out-of-line group operations: one copy of each per code object.  The doubling cases are rare
-// (equal operands).
-// 2 * (+-table[v]) for a table entry that is not the identity.  Takes the entry by index and
-// returns by value, so that no caller variable has its address taken (an address-taken
-// accumulator would live in scratch memory for the whole loop).
+// Out-of-line doublings: one copy of each per code object.  They are taken only when two equal
+// points meet in one bucket.  Arguments by index / value and results by value, so that no
+// caller variable has its address taken (an address-taken accumulator would live in scratch
+// memory for the whole loop).
 __device__ __noinline__ G1Xyzz28 dbl_entry_cold(const G1Affine28 *__restrict__ table, uint32_t v) {
     G1Affine28 pt = table[v & 0x7fffffffu];
     Fq28 y = (v >> 31) ? q28_neg(pt.y) : pt.y;
     return xyzz28_dbl_affine(pt.x, y);
 }
-__device__ __noinline__ void dbl_cold(G1Xyzz &out, const G1Xyzz &a) { out = xyzz_dbl(a); }
+__device__ __noinline__ G1Xyzz28 dbl_cold(const G1Xyzz28 *a) { return xyzz28_dbl(*a); }
 
 // ------------------------------------------------------------------------------------------
 // 1. digits
@@ -89,9 +88,8 @@ __global__ __launch_bounds__(256) void k_bounds(const uint32_t *__restrict__ key
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint32_t run_end, uint32_t seg_begin,
                                           size_t seg, const uint32_t *__restrict__ start,
-                                          G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part,
-                                          const G1Xyzz28 &acc28) {
-    const G1Xyzz acc = xyzz28_to(acc28);  // the tail kernels work on the 12 x 32-bit form
+                                          G1Xyzz28 *__restrict__ buckets, G1Xyzz28 *__restrict__ part,
+                                          const G1Xyzz28 &acc) {
     if (start[key] == run_begin && start[key + 1] == run_end) {
         buckets[key] = acc;  // the whole bucket lies inside this segment
     } else if (run_begin == seg_begin) {
@@ -101,11 +99,12 @@ __device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(kBlock, 3) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                        uint32_t seg_len, const G1Affine28 *__restrict__ table,
-                                                       G1Xyzz *__restrict__ buckets, G1Xyzz *__restrict__ part) {
+                                                       G1Xyzz28 *__restrict__ buckets,
+                                                       G1Xyzz28 *__restrict__ part) {
     size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nvalid = start[nbuckets];
     size_t begin64 = seg * seg_len;
@@ -153,15 +152,18 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const uint32_t *__restric
 // ------------------------------------------------------------------------------------------
 // Full XYZZ addition with the (rare) equal-operands case out of line: one inlined copy per
 // kernel keeps the serial tails short without blowing up the code object.
-__device__ __forceinline__ G1Xyzz add_inline(const G1Xyzz &a, const G1Xyzz &b) {
-    G1Xyzz r;
-    if (!xyzz_add_nodbl(r, a, b)) dbl_cold(r, a);
+__device__ __forceinline__ G1Xyzz28 add_inline(const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    G1Xyzz28 r;
+    if (!xyzz28_add_nodbl(r, a, b)) {
+        G1Xyzz28 t = a;  // a private copy: the caller's value keeps its registers
+        r = dbl_cold(&t);
+    }
     return r;
 }
 
 // Partial j (0-based) of a bucket whose run starts at sorted position lo: segment s0 + j;
 // only the first partial can sit in the "touches the segment end" slot.
-__device__ __forceinline__ const G1Xyzz *partial_of(const G1Xyzz *part, uint32_t s0, uint32_t j, uint32_t lo,
+__device__ __forceinline__ const G1Xyzz28 *partial_of(const G1Xyzz28 *part, uint32_t s0, uint32_t j, uint32_t lo,
                                                     uint32_t seg_len) {
     size_t s = (size_t)s0 + j;
     return part + 2 * s + ((j == 0 && lo != s0 * seg_len) ? 1 : 0);
@@ -170,15 +172,15 @@ __device__ __forceinline__ const G1Xyzz *partial_of(const G1Xyzz *part, uint32_t
 // One lane per bucket.  Buckets with more than serial_max partials (skewed digit
 // distributions: the narrow top window, repeated scalars) are queued for k_fixup_big.
 __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
-                                                  uint32_t seg_len, const G1Xyzz *__restrict__ part,
-                                                  G1Xyzz *__restrict__ buckets, uint32_t serial_max,
+                                                  uint32_t seg_len, const G1Xyzz28 *__restrict__ part,
+                                                  G1Xyzz28 *__restrict__ buckets, uint32_t serial_max,
                                                   uint32_t *__restrict__ big_count,
                                                   uint32_t *__restrict__ big_list) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     uint32_t lo = start[b], hi = start[b + 1];
     if (lo == hi) {
-        buckets[b] = xyzz_identity();
+        buckets[b] = xyzz28_identity();
         return;
     }
     uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ s
         big_list[atomicAdd(big_count, 1u)] = b;
         return;
     }
-    G1Xyzz acc = *partial_of(part, s0, 0, lo, seg_len);
+    G1Xyzz28 acc = *partial_of(part, s0, 0, lo, seg_len);
     for (uint32_t j = 1; j < cnt; j++) acc = add_inline(acc, *partial_of(part, s0, j, lo, seg_len));
     buckets[b] = acc;
 }
@@ -196,13 +198,13 @@ __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ s
 // Sum of `cnt` points fetched through `at(j)` by one 256-lane block: strided partial sums,
 // then an LDS tree.  The result is valid in lane 0.  One inlined addition serves both stages.
 template <class At>
-__device__ __forceinline__ G1Xyzz block_sum(uint32_t cnt, G1Xyzz *sh, At at) {
+__device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at) {
     const uint32_t t = threadIdx.x;
     const uint32_t strided = (cnt + kSumBlock - 1) / kSumBlock;  // uniform over the block
-    G1Xyzz acc = xyzz_identity();
-    const uint32_t steps = strided + 8;  // 8 = log2(kSumBlock) tree levels
+    G1Xyzz28 acc = xyzz28_identity();
+    const uint32_t steps = strided + 7;  // 7 = log2(kSumBlock) tree levels
     for (uint32_t step = 0; step < steps; step++) {
-        const G1Xyzz *src = nullptr;
+        const G1Xyzz28 *src = nullptr;
         if (step < strided) {
             uint32_t j = step * kSumBlock + t;
             if (j < cnt) src = at(j);
@@ -215,7 +217,7 @@ __device__ __forceinline__ G1Xyzz block_sum(uint32_t cnt, G1Xyzz *sh, At at) {
             if (t < stride) src = &sh[t + stride];
         }
         if (src) {
-            G1Xyzz o = *src;
+            G1Xyzz28 o = *src;
             acc = add_inline(acc, o);
         }
         if (step >= strided) {
@@ -229,17 +231,17 @@ __device__ __forceinline__ G1Xyzz block_sum(uint32_t cnt, G1Xyzz *sh, At at) {
 
 // One block per queued bucket (grid-stride over the queue).
 __global__ __launch_bounds__(kSumBlock) void k_fixup_big(const uint32_t *__restrict__ start, uint32_t seg_len,
-                                                         const G1Xyzz *__restrict__ part,
-                                                         G1Xyzz *__restrict__ buckets,
+                                                         const G1Xyzz28 *__restrict__ part,
+                                                         G1Xyzz28 *__restrict__ buckets,
                                                          const uint32_t *__restrict__ big_count,
                                                          const uint32_t *__restrict__ big_list) {
-    __shared__ G1Xyzz sh[kSumBlock];
+    __shared__ G1Xyzz28 sh[kSumBlock];
     const uint32_t count = *big_count;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         uint32_t b = big_list[i];
         uint32_t lo = start[b], hi = start[b + 1];
         uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
-        G1Xyzz acc = block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
+        G1Xyzz28 acc = block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
         if (threadIdx.x == 0) buckets[b] = acc;
         __syncthreads();
     }
@@ -253,22 +255,22 @@ __global__ __launch_bounds__(kSumBlock) void k_fixup_big(const uint32_t *__restr
 //   LW[t] = sum_j (j + off) A[t*kChunk + j]          (off = 1 on the bucket level, else 0)
 // by the running-sum recurrence run += A[b]; sum += run, highest b first.  Both updates go
 // through one inlined addition with selected operands.
-__global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz *__restrict__ A, uint32_t n, int off,
-                                                         G1Xyzz *__restrict__ LW, G1Xyzz *__restrict__ R,
+__global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz28 *__restrict__ A, uint32_t n, int off,
+                                                         G1Xyzz28 *__restrict__ LW, G1Xyzz28 *__restrict__ R,
                                                          uint32_t nchunks) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t lo = t * kChunk;
     uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    G1Xyzz run = xyzz_identity(), sum = xyzz_identity();
+    G1Xyzz28 run = xyzz28_identity(), sum = xyzz28_identity();
     const uint32_t steps = 2 * (hi - lo);
     for (uint32_t step = 0; step < steps; step++) {
         uint32_t b = hi - 1 - (step >> 1);
         bool to_run = (step & 1) == 0;
         if (!to_run && b == lo && !off) break;  // weight 0 for the chunk's first element
-        G1Xyzz x = to_run ? run : sum;
-        G1Xyzz y = to_run ? A[b] : run;
-        G1Xyzz r = add_inline(x, y);
+        G1Xyzz28 x = to_run ? run : sum;
+        G1Xyzz28 y = to_run ? A[b] : run;
+        G1Xyzz28 r = add_inline(x, y);
         if (to_run) {
             run = r;
         } else {
@@ -289,35 +291,35 @@ static constexpr uint32_t kSumPerBlock = 4 * kSumBlock;
 
 // Plain sums: block (x, level) adds elements [x*kSumPerBlock, (x+1)*kSumPerBlock) of that
 // level's array.
-__global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz *__restrict__ in, G1Xyzz *__restrict__ out,
+__global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz28 *__restrict__ in, G1Xyzz28 *__restrict__ out,
                                                         SumDesc d) {
-    __shared__ G1Xyzz sh[kSumBlock];
+    __shared__ G1Xyzz28 sh[kSumBlock];
     const int lev = blockIdx.y;
     const uint32_t n = d.n[lev];
     const uint32_t base = blockIdx.x * kSumPerBlock;
     if (base >= n) return;  // uniform per block
-    const G1Xyzz *src = in + d.in_off[lev] + base;
+    const G1Xyzz28 *src = in + d.in_off[lev] + base;
     uint32_t cnt = n - base < kSumPerBlock ? n - base : kSumPerBlock;
-    G1Xyzz acc = block_sum(cnt, sh, [&](uint32_t j) { return src + j; });
+    G1Xyzz28 acc = block_sum(cnt, sh, [&](uint32_t j) { return src + j; });
     if (threadIdx.x == 0) out[d.out_off[lev] + blockIdx.x] = acc;
 }
 
 // Horner over the level sums: total = s_0 + 4 (s_1 + 4 (s_2 + ...)); Jacobian result.
-__global__ void k_finish(const G1Xyzz *__restrict__ sums, SumDesc d, int nlev, G1Jac *__restrict__ out) {
+__global__ void k_finish(const G1Xyzz28 *__restrict__ sums, SumDesc d, int nlev, G1Jac *__restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    G1Xyzz acc = sums[d.in_off[nlev - 1]];
+    G1Xyzz28 acc = sums[d.in_off[nlev - 1]];
     for (int l = nlev - 2; l >= 0; l--) {
-        for (int k = 0; k < kChunkLog; k++) acc = xyzz_dbl(acc);
+        for (int k = 0; k < kChunkLog; k++) acc = xyzz28_dbl(acc);
         acc = add_inline(acc, sums[d.in_off[l]]);
     }
-    *out = xyzz_to_jac(acc);
+    *out = xyzz_to_jac(xyzz28_to(acc));
 }
 
 // out = sum of n Jacobian points (n is the number of GPUs: a handful)
 __global__ void k_sum_jac(const G1Jac *__restrict__ pts, uint32_t n, G1Jac *__restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     G1Xyzz acc = xyzz_identity();
-    for (uint32_t i = 0; i < n; i++) acc = add_inline(acc, jac_to_xyzz(pts[i]));
+    for (uint32_t i = 0; i < n; i++) acc = xyzz_add(acc, jac_to_xyzz(pts[i]));
     *out = xyzz_to_jac(acc);
 }
 
@@ -396,15 +398,15 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     PLONK_TRY(buf_reserve(ctx, ctx->vals_b, total * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
     PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
-    PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz)));
-    PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz)));
+    PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz28)));
     PLONK_TRY(buf_reserve(ctx, ctx->big_list, ((size_t)nb + 1) * 4));
 
     uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
     uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
     uint32_t *start = (uint32_t *)ctx->bucket_start.ptr;
-    G1Xyzz *buckets = (G1Xyzz *)ctx->buckets.ptr;
-    G1Xyzz *part = (G1Xyzz *)ctx->seg_part.ptr;
+    G1Xyzz28 *buckets = (G1Xyzz28 *)ctx->buckets.ptr;
+    G1Xyzz28 *part = (G1Xyzz28 *)ctx->seg_part.ptr;
     const G1Affine28 *table = (const G1Affine28 *)ctx->table.ptr;
     uint32_t *big_count = (uint32_t *)ctx->big_list.ptr, *big_list = big_count + 1;
 
@@ -442,16 +444,16 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
         if (nchunks <= 1) break;
     }
     if (nlev > kMaxLevels) return PLONK_HIP_ERR_INVALID_ARG;
-    PLONK_TRY(buf_reserve(ctx, ctx->red_a, (size_t)level_n[1] * sizeof(G1Xyzz)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_b, (size_t)(nlev > 1 ? level_n[2] : 1) * sizeof(G1Xyzz)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_lw, lw_total * sizeof(G1Xyzz)));
-    G1Xyzz *lw = (G1Xyzz *)ctx->red_lw.ptr;
+    PLONK_TRY(buf_reserve(ctx, ctx->red_a, (size_t)level_n[1] * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_b, (size_t)(nlev > 1 ? level_n[2] : 1) * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_lw, lw_total * sizeof(G1Xyzz28)));
+    G1Xyzz28 *lw = (G1Xyzz28 *)ctx->red_lw.ptr;
     SumDesc desc = {};
     {
-        const G1Xyzz *A = buckets;
+        const G1Xyzz28 *A = buckets;
         uint32_t off = 0;
         for (int l = 0; l < nlev; l++) {
-            G1Xyzz *Rbuf = (G1Xyzz *)((l & 1) ? ctx->red_b.ptr : ctx->red_a.ptr);
+            G1Xyzz28 *Rbuf = (G1Xyzz28 *)((l & 1) ? ctx->red_b.ptr : ctx->red_a.ptr);
             uint32_t nchunks = level_n[l + 1];
             hipLaunchKernelGGL(k_reduce_level, dim3(cdiv(nchunks, kBlock)), dim3(kBlock), 0, st, A, level_n[l],
                                l == 0 ? 1 : 0, lw + off, Rbuf, nchunks);
@@ -464,10 +466,10 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     // ---- plain sums of every level's LW array
     size_t max_blocks_total = 0;
     for (int l = 0; l < nlev; l++) max_blocks_total += cdiv(desc.n[l], kSumPerBlock);
-    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_a, max_blocks_total * sizeof(G1Xyzz)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_b, max_blocks_total * sizeof(G1Xyzz)));
-    const G1Xyzz *in = lw;
-    G1Xyzz *outs[2] = {(G1Xyzz *)ctx->red_sum_a.ptr, (G1Xyzz *)ctx->red_sum_b.ptr};
+    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_a, max_blocks_total * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_b, max_blocks_total * sizeof(G1Xyzz28)));
+    const G1Xyzz28 *in = lw;
+    G1Xyzz28 *outs[2] = {(G1Xyzz28 *)ctx->red_sum_a.ptr, (G1Xyzz28 *)ctx->red_sum_b.ptr};
     int flip = 0;
     while (true) {
         uint32_t max_n = 0, max_blocks = 0, off = 0;

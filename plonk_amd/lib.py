@@ -44,6 +44,9 @@ SIGNATURES = {
     "plonk_hip_msm_phase_ms": (ctypes.c_int, [c_ctx, c_floatp]),
     "plonk_hip_msm_phase_name": (ctypes.c_char_p, [ctypes.c_int]),
     "plonk_hip_bench_mad_rate": (ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_double)]),
+    "plonk_hip_bench_mad_mix": (
+        ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                       ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_fq_mul_rate": (
         ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_msm_plan": (ctypes.c_int, [c_ctx, c_intp, c_intp, c_sizep]),
