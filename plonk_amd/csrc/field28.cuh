@@ -191,6 +191,99 @@ PLONK_HD Fq28 q28_sqr(const Fq28 &a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lazy forms for the bucket-accumulation loop: limbs stay normalised (< 2^28) but values are only
+// bounded by a small multiple of q, so the conditional subtractions disappear.  Bounds are in
+// units of q and are tracked where the functions are used (g1_28.cuh).
+// ---------------------------------------------------------------------------------------------
+// limb i of K*q
+template <int K>
+PLONK_HD constexpr uint32_t q28_kq(int i) {
+    uint64_t c = 0;
+    uint32_t out = 0;
+    for (int j = 0; j <= i; j++) {
+        c += (uint64_t)K * Q28::mod(j);
+        out = (uint32_t)(c & Q28::MASK);
+        c >>= Q28::BITS;
+    }
+    return out;
+}
+
+// Montgomery product without the final conditional subtraction:
+// a < A*q, b < B*q  =>  result < (1 + A*B/2500) * q   (q / 2^392 < 1/2500).
+PLONK_HD Fq28 q28_mul_lazy(const Fq28 &a, const Fq28 &b) {
+    constexpr int N = Q28::N;
+    uint64_t acc = 0;
+    uint32_t m[N];
+    Fq28 r;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Q28::mod(k - i);
+        m[k] = ((uint32_t)acc * Q28::INV) & Q28::MASK;
+        acc += (uint64_t)m[k] * Q28::mod(0);
+        acc >>= Q28::BITS;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)m[i] * Q28::mod(k - i);
+        }
+        r.l[k - N] = (uint32_t)acc & Q28::MASK;
+        acc >>= Q28::BITS;
+    }
+    return r;
+}
+
+// (sign ? -a : a) - b + K*q in one carry pass.  Needs K*q >= b (+ a when sign is set).
+// Result < a + K*q (sign clear) or <= K*q (sign set).
+template <int K>
+PLONK_HD Fq28 q28_sub_lazy(const Fq28 &a, const Fq28 &b, bool sign = false) {
+    const int32_t sm = sign ? -1 : 0;
+    Fq28 r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        int32_t ai = ((int32_t)a.l[i] ^ sm) - sm;  // +-a_i
+        int32_t t = ai - (int32_t)b.l[i] + (int32_t)q28_kq<K>(i) + c;
+        r.l[i] = (uint32_t)t & Q28::MASK;
+        c = t >> Q28::BITS;
+    }
+    return r;
+}
+
+// a - b - 2c + K*q in one carry pass.  Needs K*q >= b + 2c.
+template <int K>
+PLONK_HD Fq28 q28_sub2_lazy(const Fq28 &a, const Fq28 &b, const Fq28 &c2) {
+    Fq28 r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] - (int32_t)(c2.l[i] << 1) + (int32_t)q28_kq<K>(i) + c;
+        r.l[i] = (uint32_t)t & Q28::MASK;
+        c = t >> Q28::BITS;
+    }
+    return r;
+}
+
+// x < 2q with normalised limbs: is x = 0 mod q?
+PLONK_HD bool q28_is_zero_mod_q(const Fq28 &x) {
+    uint32_t z = 0, d = 0;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        z |= x.l[i];
+        d |= x.l[i] ^ Q28::mod(i);
+    }
+    return z == 0 || d == 0;
+}
+
+// Any value below ~2000 q with normalised limbs -> its canonical representative.
+PLONK_HD Fq28 q28_canon(const Fq28 &x) { return q28_reduce_once(q28_mul_lazy(x, q28_one())); }
+
+// ---------------------------------------------------------------------------------------------
 // conversions to and from the 12 x 32-bit Montgomery (radix 2^384) form of field.cuh
 // ---------------------------------------------------------------------------------------------
 // plain re-slicing of a 384-bit integer (< 2^392 trivially)

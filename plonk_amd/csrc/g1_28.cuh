@@ -145,6 +145,46 @@ PLONK_HD G1Xyzz28 xyzz28_add(const G1Xyzz28 &a, const G1Xyzz28 &b) {
     return r;
 }
 
+// Lazy mixed addition for the accumulation loop: acc += (x2, negate ? -y2 : y2).
+// Preconditions: acc is not the identity; (x2, y2) canonical and not the identity;
+//   acc.x < 5.1 q, acc.y < 3.1 q, acc.zz, acc.zzz < 1.1 q   (the same bounds hold on return).
+// Returns false, with acc untouched, when x2*ZZ = X mod q (the points are equal or opposite):
+// the caller resolves that rare case on canonical values.
+PLONK_HD bool xyzz28_madd_lazy(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2, bool negate) {
+    Fq28 P = q28_sub_lazy<6>(q28_mul_lazy(x2, acc.zz), acc.x);            // U2 - X1      < 7.1 q
+    PLONK_STEP();
+    Fq28 R = q28_sub_lazy<5>(q28_mul_lazy(y2, acc.zzz), acc.y, negate);   // +-S2 - Y1    < 6.1 q
+    PLONK_STEP();
+    Fq28 PP = q28_mul_lazy(P, P);                                         //              < 1.03 q
+    if (q28_is_zero_mod_q(PP)) return false;
+    PLONK_STEP();
+    acc.zz = q28_mul_lazy(acc.zz, PP);
+    PLONK_STEP();
+    Fq28 PPP = q28_mul_lazy(P, PP);
+    PLONK_STEP();
+    acc.zzz = q28_mul_lazy(acc.zzz, PPP);
+    PLONK_STEP();
+    Fq28 Q = q28_mul_lazy(acc.x, PP);
+    PLONK_STEP();
+    Fq28 T = q28_mul_lazy(acc.y, PPP);
+    PLONK_STEP();
+    acc.x = q28_sub2_lazy<4>(q28_mul_lazy(R, R), PPP, Q);                 // R^2 - PPP - 2Q  < 5.1 q
+    PLONK_STEP();
+    acc.y = q28_sub_lazy<2>(q28_mul_lazy(R, q28_sub_lazy<6>(Q, acc.x)), T);  // R(Q - X3) - T < 3.1 q
+    return true;
+}
+
+// Canonical representative of a lazily accumulated point.
+PLONK_HD G1Xyzz28 xyzz28_canon(const G1Xyzz28 &p) {
+    if (xyzz28_is_identity(p)) return xyzz28_identity();
+    G1Xyzz28 r;
+    r.x = q28_canon(p.x);
+    r.y = q28_canon(p.y);
+    r.zz = q28_canon(p.zz);
+    r.zzz = q28_canon(p.zzz);
+    return r;
+}
+
 PLONK_HD void xyzz28_madd(G1Xyzz28 &acc, const G1Affine28 &p, bool negate) {
     if (affine28_is_identity(p)) return;
     Fq28 y = negate ? q28_neg(p.y) : p.y;

@@ -11,7 +11,8 @@
 //   3. k_bounds      first sorted position of every bucket
 //   4. k_accumulate  one lane per fixed-length SEGMENT of the sorted list: gathers the affine
 //                    table points (one 128-byte line each) and adds them into an XYZZ
-//                    accumulator (8M + 2S per point) on 28-bit limbs (field28.cuh).
+//                    accumulator (8M + 2S per point) on 28-bit limbs with lazy reduction
+//                    (field28.cuh, g1_28.cuh).
 //                    Buckets lying wholly inside a segment are written directly; runs cut by a
 //                    segment border are written as partials.  Work per lane is uniform whatever
 //                    the scalar distribution.
@@ -44,6 +45,14 @@ __device__ __noinline__ G1Xyzz28 dbl_entry_cold(const G1Affine28 *__restrict__ t
     return xyzz28_dbl_affine(pt.x, y);
 }
 __device__ __noinline__ G1Xyzz28 dbl_cold(const G1Xyzz28 *a) { return xyzz28_dbl(*a); }
+// The accumulation loop's rare case (the incoming point equals or is opposite to the
+// accumulator): redo the addition on canonical values with the complete formulas.
+__device__ __noinline__ G1Xyzz28 madd_slow_cold(const G1Xyzz28 *acc_lazy, const G1Affine28 *__restrict__ table,
+                                                uint32_t v) {
+    G1Xyzz28 acc = xyzz28_canon(*acc_lazy);
+    xyzz28_madd(acc, table[v & 0x7fffffffu], (v >> 31) != 0);
+    return acc;
+}
 
 // ------------------------------------------------------------------------------------------
 // 1. digits
@@ -137,8 +146,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_accumulate(const uint32_t *__rest
         uint32_t touch = 0;
         if (more) touch = table[vn & 0x7fffffffu].x.l[0];
         if (!affine28_is_identity(pt)) {
-            Fq28 y = (v >> 31) ? q28_neg(pt.y) : pt.y;
-            if (!xyzz28_madd_nodbl(acc, pt.x, y)) acc = dbl_entry_cold(table, v);
+            const bool neg = (v >> 31) != 0;
+            if (xyzz28_is_identity(acc)) {
+                acc.x = pt.x;
+                acc.y = neg ? q28_neg(pt.y) : pt.y;
+                acc.zz = q28_one();
+                acc.zzz = q28_one();
+            } else if (!xyzz28_madd_lazy(acc, pt.x, pt.y, neg)) {
+                G1Xyzz28 t = acc;  // a private copy: acc itself keeps its registers
+                acc = madd_slow_cold(&t, table, v);
+            }
         }
         asm volatile("" ::"v"(touch));
         k = kn;
@@ -184,20 +201,25 @@ __global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ s
         return;
     }
     uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
-    if (s0 == s1) return;  // written by k_accumulate
+    if (s0 == s1) {
+        // written whole by k_accumulate, in its lazy form: canonicalise in place
+        buckets[b] = xyzz28_canon(buckets[b]);
+        return;
+    }
     uint32_t cnt = s1 - s0 + 1;
     if (cnt > serial_max) {
         big_list[atomicAdd(big_count, 1u)] = b;
         return;
     }
-    G1Xyzz28 acc = *partial_of(part, s0, 0, lo, seg_len);
-    for (uint32_t j = 1; j < cnt; j++) acc = add_inline(acc, *partial_of(part, s0, j, lo, seg_len));
+    G1Xyzz28 acc = xyzz28_canon(*partial_of(part, s0, 0, lo, seg_len));
+    for (uint32_t j = 1; j < cnt; j++) acc = add_inline(acc, xyzz28_canon(*partial_of(part, s0, j, lo, seg_len)));
     buckets[b] = acc;
 }
 
-// Sum of `cnt` points fetched through `at(j)` by one 256-lane block: strided partial sums,
-// then an LDS tree.  The result is valid in lane 0.  One inlined addition serves both stages.
-template <class At>
+// Sum of `cnt` points fetched through `at(j)` by one block: strided partial sums, then an LDS
+// tree.  The result is valid in lane 0.  One inlined addition serves both stages.  LAZY_IN:
+// the fetched points come straight from k_accumulate and are canonicalised first.
+template <bool LAZY_IN, class At>
 __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at) {
     const uint32_t t = threadIdx.x;
     const uint32_t strided = (cnt + kSumBlock - 1) / kSumBlock;  // uniform over the block
@@ -218,6 +240,7 @@ __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at)
         }
         if (src) {
             G1Xyzz28 o = *src;
+            if (LAZY_IN && step < strided) o = xyzz28_canon(o);
             acc = add_inline(acc, o);
         }
         if (step >= strided) {
@@ -241,7 +264,8 @@ __global__ __launch_bounds__(kSumBlock) void k_fixup_big(const uint32_t *__restr
         uint32_t b = big_list[i];
         uint32_t lo = start[b], hi = start[b + 1];
         uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
-        G1Xyzz28 acc = block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
+        G1Xyzz28 acc =
+            block_sum<true>(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
         if (threadIdx.x == 0) buckets[b] = acc;
         __syncthreads();
     }
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz28 *__restri
     if (base >= n) return;  // uniform per block
     const G1Xyzz28 *src = in + d.in_off[lev] + base;
     uint32_t cnt = n - base < kSumPerBlock ? n - base : kSumPerBlock;
-    G1Xyzz28 acc = block_sum(cnt, sh, [&](uint32_t j) { return src + j; });
+    G1Xyzz28 acc = block_sum<false>(cnt, sh, [&](uint32_t j) { return src + j; });
     if (threadIdx.x == 0) out[d.out_off[lev] + blockIdx.x] = acc;
 }
 

@@ -143,3 +143,25 @@ extern "C" void hc_affine28_roundtrip(const uint32_t *aff, uint32_t *out) {
     G1Affine r = affine28_to(affine28_from(lda(aff)));
     memcpy(out, &r, sizeof(r));
 }
+
+// The accumulation loop's lazy form: same fold, lazy additions, canonicalised at the end
+// (mirrors k_accumulate + the canonicalisation of k_fixup).
+extern "C" void hc_xyzz28_fold_lazy(const uint32_t *aff, const int *negate, size_t n, uint32_t *out_xyzz) {
+    G1Xyzz28 acc = xyzz28_identity();
+    for (size_t i = 0; i < n; i++) {
+        G1Affine28 p = affine28_from(lda(aff + 24 * i));
+        if (affine28_is_identity(p)) continue;
+        bool neg = negate[i] != 0;
+        if (xyzz28_is_identity(acc)) {
+            acc.x = p.x;
+            acc.y = neg ? q28_neg(p.y) : p.y;
+            acc.zz = q28_one();
+            acc.zzz = q28_one();
+        } else if (!xyzz28_madd_lazy(acc, p.x, p.y, neg)) {
+            acc = xyzz28_canon(acc);
+            xyzz28_madd(acc, p, neg);
+        }
+    }
+    G1Xyzz r = xyzz28_to(xyzz28_canon(acc));
+    memcpy(out_xyzz, &r, sizeof(r));
+}

@@ -171,12 +171,18 @@ def test_28_bit_bucket_accumulation(hc):
     aff = c.g1_to_affine(np.stack(pts))
     ident_aff = np.zeros(12, dtype=np.uint64)
 
-    def fold(seq):
+    def fold_with(fn, seq):
         a = np.ascontiguousarray(np.stack([x for x, _ in seq]))
         neg = (ctypes.c_int * len(seq))(*[int(s) for _, s in seq])
         out = np.empty(24, dtype=np.uint64)
-        hc.hc_xyzz28_fold(_p32(a), neg, ctypes.c_size_t(len(seq)), _p32(out))
+        fn(_p32(a), neg, ctypes.c_size_t(len(seq)), _p32(out))
         return _xyzz_to_point(hc, out)
+
+    def fold(seq):
+        strict = fold_with(hc.hc_xyzz28_fold, seq)
+        lazy = fold_with(hc.hc_xyzz28_fold_lazy, seq)  # the accumulation loop's lazy arithmetic
+        assert o.g1_to_affine(strict) == o.g1_to_affine(lazy)
+        return lazy
 
     rt = np.empty(12, dtype=np.uint64)
     hc.hc_affine28_roundtrip(_p32(np.ascontiguousarray(aff[0])), _p32(rt))
@@ -189,7 +195,7 @@ def test_28_bit_bucket_accumulation(hc):
     assert o.g1_eq(fold([(ident_aff, 0), (aff[1], 0), (ident_aff, 1)]), ref[1])    # identity operands
     want = o.G1_IDENTITY
     seq = []
-    for i in range(40):
+    for i in range(400):
         j, sgn = rnd.randrange(5), rnd.randrange(2)
         seq.append((aff[j], sgn))
         want = o.g1_add(want, o.g1_neg(ref[j]) if sgn else ref[j])
