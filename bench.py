@@ -126,15 +126,22 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PLONK_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks then share devices and the 144-byte partials are staged through the host)
+    backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import plonk_amd
 
-    be = plonk_amd.Backend(device=local_rank, window_bits=args.window_bits)
+    be = plonk_amd.Backend(device=device_index, window_bits=args.window_bits)
     n_total = 1 << args.log_n
     assert n_total % world == 0
     n_local = n_total // world
@@ -179,7 +186,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

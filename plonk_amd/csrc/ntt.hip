@@ -10,14 +10,15 @@
 //   DIT  bit-reversed in   -> natural order out        (stages low to high)
 // The public transform is natural order on both sides (DIF + bit-reversal, or bit-reversal
 // + DIT); the quotient pipeline chains DIF -> pointwise -> DIT and never permutes.
-// Twiddles omega^e, e < n/2, are precomputed per size and direction and cached in the context.
+// Inside a pass the butterflies run on 29-bit limbs (field29.cuh) with lazy reduction; every lane
+// keeps 8 elements in registers and does up to 3 stages (12 butterflies) per LDS round trip.
+// Twiddles omega^e, e < n/2, are precomputed per size and direction (as w * 2^261 in 29-bit
+// limbs) and cached in the context.
 #include "context.hpp"
+#include "field29.cuh"
 #include "poly.hpp"
 
 namespace plonk {
-
-static constexpr int kMaxTileLog = 10;  // 1024 elements = 32 KiB of LDS
-static constexpr int kNttBlock = 256;
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -75,6 +76,23 @@ __global__ __launch_bounds__(256) void k_pow_combine(const Fr *__restrict__ lo, 
     if (e >> 10) v = fe_mul(v, hi[e >> 10]);
     out[e] = v;
 }
+// twiddle entry: 9 x 29-bit limbs padded to 48 bytes (three 16-byte loads)
+struct alignas(16) Tw29 {
+    Fr29 v;
+    uint32_t pad[3];
+};
+// out[e] = (lo[e & 1023] * hi[e >> 10]) * 2^261 in 29-bit limbs
+__global__ __launch_bounds__(256) void k_twiddle29(const Fr *__restrict__ lo, const Fr *__restrict__ hi, size_t count,
+                                                  Tw29 *__restrict__ out) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    Fr v = lo[e & 1023];
+    if (e >> 10) v = fe_mul(v, hi[e >> 10]);
+    Tw29 t;
+    t.v = fr29_twiddle_from(v);
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    out[e] = t;
+}
 // data[b][i] *= lo[i & 1023] * hi[i >> 10]
 __global__ __launch_bounds__(256) void k_scale_two_level(Fr *__restrict__ data, size_t n, size_t batch_stride,
                                                         const Fr *__restrict__ lo, const Fr *__restrict__ hi) {
@@ -117,7 +135,7 @@ int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, cons
     return PLONK_HIP_OK;
 }
 
-static int get_twiddles(plonk_hip_ctx *ctx, uint32_t log_n, bool inverse, const Fr **out) {
+static int get_twiddles(plonk_hip_ctx *ctx, uint32_t log_n, bool inverse, const Tw29 **out) {
     DevBuf &b = ctx->twiddle[inverse ? 1 : 0][log_n];
     size_t count = log_n ? ((size_t)1 << (log_n - 1)) : 1;
     if (!b.ptr) {
@@ -125,59 +143,190 @@ static int get_twiddles(plonk_hip_ctx *ctx, uint32_t log_n, bool inverse, const 
         if (inverse) w = fe_inv(w);
         const Fr *lo, *hi;
         PLONK_TRY(build_two_level(ctx, w, count, &lo, &hi));
-        PLONK_TRY(buf_reserve(ctx, b, count * sizeof(Fr)));
-        hipLaunchKernelGGL(k_pow_combine, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, lo, hi, count,
-                           (Fr *)b.ptr);
+        PLONK_TRY(buf_reserve(ctx, b, count * sizeof(Tw29)));
+        hipLaunchKernelGGL(k_twiddle29, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, lo, hi, count,
+                           (Tw29 *)b.ptr);
     }
-    *out = (const Fr *)b.ptr;
+    *out = (const Tw29 *)b.ptr;
     return PLONK_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // butterfly passes
 // ------------------------------------------------------------------------------------------
+// LDS image of a tile: element j at word 9*j + (j >> 5) (odd stride plus one pad word per 32
+// elements keeps the strided accesses of every round spread over the banks).
+__device__ __forceinline__ uint32_t lds_word(uint32_t j) { return 9u * j + (j >> 5); }
+__device__ __forceinline__ Fr29 lds_get(const uint32_t *tile, uint32_t j) {
+    Fr29 v;
+    const uint32_t *p = tile + lds_word(j);
+#pragma unroll
+    for (int i = 0; i < R29::N; i++) v.l[i] = p[i];
+    return v;
+}
+__device__ __forceinline__ void lds_put(uint32_t *tile, uint32_t j, const Fr29 &v) {
+    uint32_t *p = tile + lds_word(j);
+#pragma unroll
+    for (int i = 0; i < R29::N; i++) p[i] = v.l[i];
+}
+
+// One round: G butterfly stages on the in-tile bits [b0, b0 + G).  A call handles NE elements:
+// NE / 2^G groups of 2^G elements whose tile indices differ exactly in those bits; `item` is the
+// work item's index inside the tile (tile_n / 8 of them).
+// Bounds (units of 2^255, capacity 64): DIT lets values grow by at most 1.81 per stage (19.4 after
+// the 10 stages of a pass, reduced when the pass stores); DIF reduces each sum back below 1.24.
+template <bool DIF, int G, int NE>
+__device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_t b0, uint32_t s0, uint32_t log_n,
+                                          size_t t_lo, const Tw29 *__restrict__ tw) {
+    constexpr uint32_t GROUP = 1u << G, GPT = (uint32_t)NE >> G, TW_PER_GROUP = GROUP - 1;
+    Fr29 x[NE];
+    uint32_t jj[NE];
+    const uint32_t low_mask = (1u << b0) - 1;
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; u++) {
+        const uint32_t gid = item * GPT + u;
+#pragma unroll
+        for (uint32_t c = 0; c < GROUP; c++) {
+            const uint32_t j = ((gid >> b0) << (b0 + G)) | (c << b0) | (gid & low_mask);
+            jj[u * GROUP + c] = j;
+            x[u * GROUP + c] = lds_get(tile, j);
+        }
+    }
+    // Twiddles of the whole round, requested up front so that their latencies overlap: stage bb
+    // of a group needs 2^bb distinct factors (one per value of the group bits below bb).
+    Fr29 twr[GPT * TW_PER_GROUP];
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; u++) {
+#pragma unroll
+        for (int bb = 0; bb < G; bb++) {
+            const uint32_t st = s0 + b0 + bb;  // global stage: half-span 2^st
+            const uint32_t emask = (1u << (b0 + bb)) - 1;
+#pragma unroll
+            for (uint32_t cl = 0; cl < (1u << bb); cl++) {
+                const size_t e = ((((size_t)(jj[u * GROUP + cl] & emask)) << s0) | t_lo) << (log_n - 1 - st);
+                twr[u * TW_PER_GROUP + ((1u << bb) - 1) + cl] = tw[e].v;
+            }
+        }
+    }
+#pragma unroll
+    for (int step = 0; step < G; step++) {
+        const int bb = DIF ? (G - 1 - step) : step;
+#pragma unroll
+        for (uint32_t u = 0; u < GPT; u++) {
+#pragma unroll
+            for (uint32_t c = 0; c < GROUP; c++) {
+                if (c & (1u << bb)) continue;
+                const uint32_t lo = u * GROUP + c, hi = lo | (1u << bb);
+                const Fr29 &w = twr[u * TW_PER_GROUP + ((1u << bb) - 1) + (c & ((1u << bb) - 1))];
+                if (DIF) {
+                    Fr29 sum = fr29_reduce_step(fr29_add_lazy(x[lo], x[hi]));
+                    x[hi] = fr29_mul_lazy(fr29_sub_lazy<2>(x[lo], x[hi]), w);
+                    x[lo] = sum;
+                } else {
+                    Fr29 t = fr29_mul_lazy(x[hi], w);
+                    x[hi] = fr29_sub_lazy<2>(x[lo], t);
+                    x[lo] = fr29_add_lazy(x[lo], t);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < (uint32_t)NE; e++) lds_put(tile, jj[e], x[e]);
+}
+
+// One pass over the stages [s0, s1) (3 <= s1 - s0 <= 11).  A block owns `tiles_per_block`
+// consecutive tiles (several when tiles are small, so that all lanes have work).  Elements
+// cross HBM as 8 x 32-bit limbs (values below 2^256; canonical when `canonical_out` is set, as
+// on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is set.
 template <bool DIF>
-__global__ __launch_bounds__(kNttBlock) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
-                                                       const Fr *__restrict__ tw, size_t batch_stride, Fr scale,
-                                                       int do_scale) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    Fr *tile = reinterpret_cast<Fr *>(smem);
+__global__ __launch_bounds__(256) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
+                                                  uint32_t tpb_log, const Tw29 *__restrict__ tw, size_t batch_stride,
+                                                  Fr29 scale, int do_scale, int canonical_out) {
+    extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t k = s1 - s0;
     const uint32_t tile_n = 1u << k;
-    const size_t T = blockIdx.x;
-    const size_t t_lo = T & (((size_t)1 << s0) - 1);
-    const size_t t_hi = T >> s0;
-    Fr *base = data + (size_t)blockIdx.y * batch_stride + (t_hi << s1) + t_lo;
+    const uint32_t tile_words = 9u * tile_n + (tile_n >> 5) + 1;
+    const uint32_t block_elems = tile_n << tpb_log;
+    Fr *vec = data + (size_t)blockIdx.y * batch_stride;
+    const size_t first_tile = (size_t)blockIdx.x << tpb_log;
+    const size_t s0_mask = ((size_t)1 << s0) - 1;
 
-    for (uint32_t j = threadIdx.x; j < tile_n; j += kNttBlock) tile[j] = base[(size_t)j << s0];
+    for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
+        const uint32_t tb = q >> k, j = q & (tile_n - 1);
+        const size_t T = first_tile + tb;
+        const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
+        lds_put(lds + tb * tile_words, j, fr29_pack(vec[idx]));
+    }
     __syncthreads();
 
-    for (uint32_t step = 0; step < k; step++) {
-        const uint32_t bl = DIF ? (k - 1 - step) : step;  // in-tile bit of this stage
-        const uint32_t st = s0 + bl;                      // global stage: half-span 2^st
-        const uint32_t low_mask = (1u << bl) - 1;
-        for (uint32_t b = threadIdx.x; b < (tile_n >> 1); b += kNttBlock) {
-            uint32_t jlo = ((b >> bl) << (bl + 1)) | (b & low_mask);
-            uint32_t jhi = jlo + (1u << bl);
-            size_t e = ((((size_t)(jlo & low_mask)) << s0) | t_lo) << (log_n - 1 - st);
-            Fr w = tw[e];
-            Fr x = tile[jlo], y = tile[jhi];
-            if (DIF) {
-                tile[jlo] = fe_add(x, y);
-                tile[jhi] = fe_mul(fe_sub(x, y), w);
+    const uint32_t items_per_tile = tile_n >> 3, items = items_per_tile << tpb_log;
+    const uint32_t nrounds = (k + 2) / 3;
+    for (uint32_t r = 0; r < nrounds; r++) {
+        // DIT walks the in-tile bits upwards, DIF downwards; the last round takes what is left
+        uint32_t g, b0;
+        if (DIF) {
+            uint32_t top = k - 3 * r;
+            g = top < 3 ? top : 3;
+            b0 = top - g;
+        } else {
+            b0 = 3 * r;
+            g = k - b0 < 3 ? k - b0 : 3;
+        }
+        for (uint32_t w = threadIdx.x; w < items; w += blockDim.x) {
+            const uint32_t tb = w / items_per_tile, item = w % items_per_tile;
+            const size_t t_lo = (first_tile + tb) & s0_mask;
+            uint32_t *tile = lds + tb * tile_words;
+            if (g == 3) {
+                ntt_round<DIF, 3, 8>(tile, item, b0, s0, log_n, t_lo, tw);
+            } else if (g == 2) {
+                // two groups of four, one after the other (keeps the register footprint of this
+                // rarely taken branch below that of the three-stage round)
+#pragma unroll 1
+                for (uint32_t h = 0; h < 2; h++) ntt_round<DIF, 2, 4>(tile, 2 * item + h, b0, s0, log_n, t_lo, tw);
             } else {
-                y = fe_mul(y, w);
-                tile[jlo] = fe_add(x, y);
-                tile[jhi] = fe_sub(x, y);
+                ntt_round<DIF, 1, 8>(tile, item, b0, s0, log_n, t_lo, tw);
             }
         }
         __syncthreads();
     }
 
-    for (uint32_t j = threadIdx.x; j < tile_n; j += kNttBlock) {
-        Fr v = tile[j];
-        if (do_scale) v = fe_mul(v, scale);
-        base[(size_t)j << s0] = v;
+    for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
+        const uint32_t tb = q >> k, j = q & (tile_n - 1);
+        const size_t T = first_tile + tb;
+        const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
+        Fr29 v = lds_get(lds + tb * tile_words, j);
+        if (do_scale) {
+            v = fr29_mul_lazy(v, scale);  // below r + 20/64 * 2^255 < 2r
+        } else {
+            v = fr29_reduce_below_2_256(v);
+        }
+        if (canonical_out) v = fr29_cond_sub(v);
+        vec[idx] = fr29_unpack(v);
+    }
+}
+
+// Transforms of 2 or 4 points (tiles too small for the register rounds): one lane per vector,
+// natural order in and out, on the 8 x 32-bit Montgomery form; w4 is the primitive 4th root.
+__global__ void k_ntt_tiny(Fr *__restrict__ data, uint32_t log_n, size_t batch, Fr w4, Fr scale, int do_scale) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    Fr *v = data + (b << log_n);
+    if (log_n == 1) {
+        Fr x = v[0], y = v[1];
+        v[0] = fe_add(x, y);
+        v[1] = fe_sub(x, y);
+    } else {
+        // natural order in and out: X_j = sum_i x_i w4^(ij)
+        Fr x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+        Fr e0 = fe_add(x0, x2), e1 = fe_sub(x0, x2);
+        Fr o0 = fe_add(x1, x3), o1 = fe_mul(fe_sub(x1, x3), w4);
+        v[0] = fe_add(e0, o0);
+        v[1] = fe_add(e1, o1);
+        v[2] = fe_sub(e0, o0);
+        v[3] = fe_sub(e1, o1);
+    }
+    if (do_scale) {
+        for (uint32_t i = 0; i < (1u << log_n); i++) v[i] = fe_mul(v[i], scale);
     }
 }
 
@@ -194,10 +343,13 @@ __global__ __launch_bounds__(256) void k_bitrev_swap(Fr *__restrict__ data, uint
     }
 }
 
+static constexpr int kMaxTileLog = 11;  // 2048 elements = 74 KiB of LDS
+
 struct PassPlan {
     int npass;
     uint32_t s0[4], s1[4];
 };
+// log_n >= 3: ceil(log_n / 11) passes of nearly equal width (each at least 3 stages)
 static PassPlan make_plan(uint32_t log_n) {
     PassPlan p;
     p.npass = (int)((log_n + kMaxTileLog - 1) / kMaxTileLog);
@@ -212,26 +364,53 @@ static PassPlan make_plan(uint32_t log_n) {
 }
 
 // DIF (natural -> bit-reversed) or DIT (bit-reversed -> natural) butterflies over `batch`
-// vectors; `scale` (if given) multiplies every output element in the last pass.
+// vectors of 2^log_n elements; `scale` (if given, radix-2^256 Montgomery form) multiplies
+// every output element in the last pass.  Outputs are canonical.
 static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, bool inverse_tw, bool dif,
                       const Fr *scale) {
-    const Fr *tw;
+    const size_t n = (size_t)1 << log_n;
+    if (log_n <= 2) {
+        // 2 or 4 points: natural-order transform plus the permutation the caller expects;
+        // omega_4 (or its inverse) is the only non-trivial factor
+        Fr w4 = fr_root_of_unity(2);
+        if (inverse_tw) w4 = fe_inv(w4);
+        Fr one = fe_one<FrCfg>();
+        if (!dif) hipLaunchKernelGGL(k_bitrev_swap, dim3(1, (unsigned)batch), dim3(256), 0, ctx->stream, d, log_n, n);
+        hipLaunchKernelGGL(k_ntt_tiny, dim3(cdiv(batch, 64)), dim3(64), 0, ctx->stream, d, log_n, batch, w4,
+                           scale ? *scale : one, scale ? 1 : 0);
+        if (dif) hipLaunchKernelGGL(k_bitrev_swap, dim3(1, (unsigned)batch), dim3(256), 0, ctx->stream, d, log_n, n);
+        return PLONK_HIP_OK;
+    }
+    const Tw29 *tw;
     PLONK_TRY(get_twiddles(ctx, log_n, inverse_tw, &tw));
     PassPlan pl = make_plan(log_n);
-    const size_t n = (size_t)1 << log_n;
-    Fr sc = scale ? *scale : fe_one<FrCfg>();
+    Fr29 sc = scale ? fr29_twiddle_from(*scale) : Fr29{};
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        lds_opt_in = true;
+    }
     for (int q = 0; q < pl.npass; q++) {
         int i = dif ? pl.npass - 1 - q : q;
         uint32_t k = pl.s1[i] - pl.s0[i];
         bool last = q == pl.npass - 1;
-        dim3 grid((unsigned)(n >> k), (unsigned)batch);
-        size_t lds = ((size_t)1 << k) * sizeof(Fr);
+        // small tiles: several per block so that a block has 1024 elements (128 work items)
+        uint32_t tpb_log = k < 10 ? 10 - k : 0;
+        if ((n >> k) < ((size_t)1 << tpb_log)) tpb_log = (uint32_t)(log_n - k);
+        const uint32_t tile_n = 1u << k;
+        const size_t lds = (size_t)(9 * tile_n + (tile_n >> 5) + 1) * 4 << tpb_log;
+        const unsigned threads = k >= 11 ? 256 : 128;
+        dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
         if (dif) {
-            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(kNttBlock), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
-                               tw, n, sc, (last && scale) ? 1 : 0);
+            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
+                               tpb_log, tw, n, sc, (last && scale) ? 1 : 0, last ? 1 : 0);
         } else {
-            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(kNttBlock), lds, ctx->stream, d, log_n, pl.s0[i],
-                               pl.s1[i], tw, n, sc, (last && scale) ? 1 : 0);
+            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
+                               tpb_log, tw, n, sc, (last && scale) ? 1 : 0, last ? 1 : 0);
         }
     }
     return PLONK_HIP_OK;
@@ -241,21 +420,19 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
     if (log_n > 30 || batch > 65535) return PLONK_HIP_ERR_INVALID_ARG;
     if (batch == 0 || log_n == 0) return PLONK_HIP_OK;  // one point: f(shift * 1) = f_0 either way
     const size_t n = (size_t)1 << log_n;
+    Fr ninv = fe_inv(fr_from_u64(n));
+    if (coset_shift && inverse && fe_is_zero(*coset_shift)) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
+    if (!inverse && coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
     if (!inverse) {
-        if (coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
         PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr));
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);
     } else {
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);
-        Fr ninv = fe_inv(fr_from_u64(n));
         PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv));
-        if (coset_shift) {
-            if (fe_is_zero(*coset_shift)) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
-            PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, fe_inv(*coset_shift)));
-        }
     }
+    if (inverse && coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, fe_inv(*coset_shift)));
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }

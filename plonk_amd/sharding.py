@@ -27,7 +27,13 @@ def gather_partials(local_pt, gathered=None, group=None):
     world = dist.get_world_size(group)
     if gathered is None:
         gathered = torch.empty(world * G1_LIMBS, dtype=local_pt.dtype, device=local_pt.device)
-    dist.all_gather_into_tensor(gathered, local_pt.contiguous(), group=group)
+    if local_pt.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a box without RCCL peers: stage the 144-byte partials through the host
+        staged = torch.empty(world * G1_LIMBS, dtype=local_pt.dtype)
+        dist.all_gather_into_tensor(staged, local_pt.cpu().contiguous(), group=group)
+        gathered.copy_(staged)
+    else:
+        dist.all_gather_into_tensor(gathered, local_pt.contiguous(), group=group)
     return gathered.view(world, G1_LIMBS)
 
 

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../plonk_amd/csrc/g1.cuh"
+#include "../../plonk_amd/csrc/field29.cuh"
 #include "../../plonk_amd/csrc/g1_28.cuh"
 #include "../../plonk_amd/csrc/msm_core.cuh"
 
@@ -164,4 +165,35 @@ extern "C" void hc_xyzz28_fold_lazy(const uint32_t *aff, const int *negate, size
     }
     G1Xyzz r = xyzz28_to(xyzz28_canon(acc));
     memcpy(out_xyzz, &r, sizeof(r));
+}
+
+// 29-bit limb form of Fr (NTT butterflies).  x, w: radix-2^256 Montgomery limbs (8 x u32).
+extern "C" void hc_fr29_mul(const uint32_t *x, const uint32_t *w, uint32_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        Fr29 a = fr29_pack(ld<FrCfg>(x + 8 * i));
+        Fr29 t = fr29_twiddle_from(ld<FrCfg>(w + 8 * i));
+        st<FrCfg>(out + 8 * i, fr29_unpack(fr29_canon(fr29_mul_lazy(a, t))));
+    }
+}
+// A lazy butterfly chain: acc <- (acc + x*w, acc - x*w + 2r) alternately, `steps` times, then
+// canonicalised: checks the add / sub / reduce helpers against plain modular arithmetic.
+extern "C" void hc_fr29_chain(const uint32_t *x, const uint32_t *w, int steps, uint32_t *out_sum, uint32_t *out_diff) {
+    Fr29 a = fr29_pack(ld<FrCfg>(x)), b = fr29_pack(ld<FrCfg>(x + 8));
+    Fr29 t = fr29_twiddle_from(ld<FrCfg>(w));
+    for (int i = 0; i < steps; i++) {
+        Fr29 m = fr29_mul_lazy(b, t);
+        Fr29 s = fr29_add_lazy(a, m);
+        Fr29 d = fr29_sub_lazy<2>(a, m);
+        a = s;
+        b = d;
+        if ((i % 5) == 4) {
+            a = fr29_reduce_below_2_256(a);
+            b = fr29_reduce_below_2_256(b);
+        }
+    }
+    st<FrCfg>(out_sum, fr29_unpack(fr29_canon(a)));
+    st<FrCfg>(out_diff, fr29_unpack(fr29_canon(b)));
+}
+extern "C" void hc_fr29_roundtrip(const uint32_t *x, uint32_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) st<FrCfg>(out + 8 * i, fr29_unpack(fr29_pack(ld<FrCfg>(x + 8 * i))));
 }

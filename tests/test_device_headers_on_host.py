@@ -200,3 +200,27 @@ def test_28_bit_bucket_accumulation(hc):
         seq.append((aff[j], sgn))
         want = o.g1_add(want, o.g1_neg(ref[j]) if sgn else ref[j])
     assert o.g1_eq(fold(seq), want)
+
+
+def test_29_bit_limb_form_of_fr(hc):
+    rnd = random.Random(33)
+    xs = [rnd.randrange(o.R) for _ in range(200)] + [0, 1, o.R - 1, o.R - 1]
+    ws = [rnd.randrange(o.R) for _ in range(200)] + [o.R - 1, 0, o.R - 1, 1]
+    X, W = c.fr_to_mont(xs), c.fr_to_mont(ws)
+    assert np.array_equal(_vec1(hc.hc_fr29_roundtrip, X), X)
+    # any 256-bit pattern survives the re-slicing
+    raw = np.frombuffer(rnd.randbytes(32 * 50), dtype=np.uint64).reshape(50, 4).copy()
+    assert np.array_equal(_vec1(hc.hc_fr29_roundtrip, raw), raw)
+    assert c.fr_from_mont(_vec2(hc.hc_fr29_mul, X, W)) == [x * w % o.R for x, w in zip(xs, ws)]
+    # lazy butterfly chain
+    for steps in (1, 4, 5, 9, 10, 20):
+        a, b, w = rnd.randrange(o.R), rnd.randrange(o.R), rnd.randrange(o.R)
+        AB = np.ascontiguousarray(c.fr_to_mont([a, b]))
+        Wm = np.ascontiguousarray(c.fr_to_mont([w]))
+        s_out = np.empty(4, dtype=np.uint64)
+        d_out = np.empty(4, dtype=np.uint64)
+        hc.hc_fr29_chain(_p32(AB), _p32(Wm), steps, _p32(s_out), _p32(d_out))
+        for _ in range(steps):
+            m = b * w % o.R
+            a, b = (a + m) % o.R, (a - m) % o.R
+        assert c.fr_from_mont(s_out)[0] == a and c.fr_from_mont(d_out)[0] == b
