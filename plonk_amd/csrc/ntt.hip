@@ -93,15 +93,35 @@ __global__ __launch_bounds__(256) void k_twiddle29(const Fr *__restrict__ lo, co
     t.pad[0] = t.pad[1] = t.pad[2] = 0;
     out[e] = t;
 }
-// data[b][i] *= lo[i & 1023] * hi[i >> 10]
+// out[i] = base^i * 2^261 in 29-bit limbs (the multiplier form of the lazy product)
+__global__ __launch_bounds__(256) void k_pow_table29(PowSeed seed, uint32_t count, Tw29 *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr acc = fe_one<FrCfg>();
+#pragma unroll 1
+    for (int k = 0; k < 32; k++) {
+        if ((i >> k) & 1) acc = fe_mul(acc, seed.pw[k]);
+    }
+    Tw29 t;
+    t.v = fr29_twiddle_from(acc);
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    out[i] = t;
+}
+// data[b][i] *= lo[i & 1023] * hi[i >> 10] for the vectors b of one batch group: the factor is
+// formed once per lane and reused for every vector of the group.  Inputs canonical, outputs canonical.
+static constexpr unsigned kScaleGroup = 8;
 __global__ __launch_bounds__(256) void k_scale_two_level(Fr *__restrict__ data, size_t n, size_t batch_stride,
-                                                        const Fr *__restrict__ lo, const Fr *__restrict__ hi) {
+                                                        unsigned batch, const Tw29 *__restrict__ lo,
+                                                        const Tw29 *__restrict__ hi) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr v = lo[i & 1023];
-    if (i >> 10) v = fe_mul(v, hi[i >> 10]);
-    Fr *p = data + (size_t)blockIdx.y * batch_stride + i;
-    *p = fe_mul(*p, v);
+    Fr29 v = lo[i & 1023].v;
+    if (i >> 10) v = fr29_cond_sub(fr29_mul_lazy(v, hi[i >> 10].v));
+    const unsigned b0 = blockIdx.y * kScaleGroup, b1 = min(batch, b0 + kScaleGroup);
+    for (unsigned b = b0; b < b1; b++) {
+        Fr *p = data + (size_t)b * batch_stride + i;
+        *p = fr29_unpack(fr29_cond_sub(fr29_mul_lazy(fr29_pack(*p), v)));
+    }
 }
 
 static PowSeed make_seed(const Fr &base) {
@@ -124,14 +144,27 @@ static int build_two_level(plonk_hip_ctx *ctx, const Fr &base, size_t count, con
     *hi = d_hi;
     return PLONK_HIP_OK;
 }
+// the same tables in the 29-bit multiplier form
+static int build_two_level29(plonk_hip_ctx *ctx, const Fr &base, size_t count, const Tw29 **lo, const Tw29 **hi) {
+    size_t nhi = (count + 1023) / 1024;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_b, (1024 + nhi) * sizeof(Tw29)));
+    Tw29 *d_lo = (Tw29 *)ctx->scratch_b.ptr, *d_hi = d_lo + 1024;
+    PowSeed s = make_seed(base);
+    hipLaunchKernelGGL(k_pow_table29, dim3(4), dim3(256), 0, ctx->stream, s, 1024u, d_lo);
+    PowSeed sh = make_seed(s.pw[10]);
+    hipLaunchKernelGGL(k_pow_table29, dim3(cdiv(nhi, 256)), dim3(256), 0, ctx->stream, sh, (uint32_t)nhi, d_hi);
+    *lo = d_lo;
+    *hi = d_hi;
+    return PLONK_HIP_OK;
+}
 
 int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, const Fr &w) {
     if (n == 0 || batch == 0) return PLONK_HIP_OK;
     if (n > 0xffffffffull || batch > 65535) return PLONK_HIP_ERR_INVALID_ARG;
-    const Fr *lo, *hi;
-    PLONK_TRY(build_two_level(ctx, w, n, &lo, &hi));
-    hipLaunchKernelGGL(k_scale_two_level, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, n, n,
-                       lo, hi);
+    const Tw29 *lo, *hi;
+    PLONK_TRY(build_two_level29(ctx, w, n, &lo, &hi));
+    hipLaunchKernelGGL(k_scale_two_level, dim3(cdiv(n, 256), cdiv(batch, kScaleGroup)), dim3(256), 0, ctx->stream,
+                       d_data, n, n, (unsigned)batch, lo, hi);
     return PLONK_HIP_OK;
 }
 
@@ -237,11 +270,12 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
 // One pass over the stages [s0, s1) (3 <= s1 - s0 <= 11).  A block owns `tiles_per_block`
 // consecutive tiles (several when tiles are small, so that all lanes have work).  Elements
 // cross HBM as 8 x 32-bit limbs (values below 2^256; canonical when `canonical_out` is set, as
-// on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is set.
+// on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is 1; with
+// do_scale 2 (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
 template <bool DIF>
 __global__ __launch_bounds__(256) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
                                                   uint32_t tpb_log, const Tw29 *__restrict__ tw, size_t batch_stride,
-                                                  Fr29 scale, int do_scale, int canonical_out) {
+                                                  Fr29 scale, Fr29 scale_upper, int do_scale, int canonical_out) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t k = s1 - s0;
     const uint32_t tile_n = 1u << k;
@@ -295,7 +329,9 @@ __global__ __launch_bounds__(256) void k_ntt_pass(Fr *__restrict__ data, uint32_
         const size_t T = first_tile + tb;
         const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
         Fr29 v = lds_get(lds + tb * tile_words, j);
-        if (do_scale) {
+        if (do_scale == 2) {
+            v = fr29_mul_lazy(v, (idx >> (log_n - 1)) ? scale_upper : scale);
+        } else if (do_scale) {
             v = fr29_mul_lazy(v, scale);  // below r + 20/64 * 2^255 < 2r
         } else {
             v = fr29_reduce_below_2_256(v);
@@ -343,6 +379,16 @@ __global__ __launch_bounds__(256) void k_bitrev_swap(Fr *__restrict__ data, uint
     }
 }
 
+// Evaluations on the coset g*<omega_2k> in bit-reversed order: position p holds the point
+// g * omega^rev(p); (g omega^e)^k - 1 = g^k (-1)^e - 1 and e is even exactly when p < k.
+__global__ __launch_bounds__(256) void k_mul_halves(Fr *__restrict__ data, size_t n, size_t batch_stride, Fr lo_half,
+                                                   Fr hi_half) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    Fr *q = data + (size_t)blockIdx.y * batch_stride + p;
+    *q = fe_mul(*q, p < n / 2 ? lo_half : hi_half);
+}
+
 static constexpr int kMaxTileLog = 11;  // 2048 elements = 74 KiB of LDS
 
 struct PassPlan {
@@ -367,7 +413,7 @@ static PassPlan make_plan(uint32_t log_n) {
 // vectors of 2^log_n elements; `scale` (if given, radix-2^256 Montgomery form) multiplies
 // every output element in the last pass.  Outputs are canonical.
 static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, bool inverse_tw, bool dif,
-                      const Fr *scale) {
+                      const Fr *scale, const Fr *scale_upper = nullptr) {
     const size_t n = (size_t)1 << log_n;
     if (log_n <= 2) {
         // 2 or 4 points: natural-order transform plus the permutation the caller expects;
@@ -377,14 +423,22 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         Fr one = fe_one<FrCfg>();
         if (!dif) hipLaunchKernelGGL(k_bitrev_swap, dim3(1, (unsigned)batch), dim3(256), 0, ctx->stream, d, log_n, n);
         hipLaunchKernelGGL(k_ntt_tiny, dim3(cdiv(batch, 64)), dim3(64), 0, ctx->stream, d, log_n, batch, w4,
-                           scale ? *scale : one, scale ? 1 : 0);
+                           scale ? *scale : one, (scale && !scale_upper) ? 1 : 0);
         if (dif) hipLaunchKernelGGL(k_bitrev_swap, dim3(1, (unsigned)batch), dim3(256), 0, ctx->stream, d, log_n, n);
+        if (scale_upper) {
+            hipLaunchKernelGGL(k_mul_halves, dim3(1, (unsigned)batch), dim3(256), 0, ctx->stream, d, n, n, *scale,
+                               *scale_upper);
+        }
         return PLONK_HIP_OK;
     }
     const Tw29 *tw;
     PLONK_TRY(get_twiddles(ctx, log_n, inverse_tw, &tw));
     PassPlan pl = make_plan(log_n);
+    // the split scale needs the s0 = 0 pass to come last, as it does for DIF
+    if (scale_upper && (!dif || !scale)) return PLONK_HIP_ERR_INVALID_ARG;
     Fr29 sc = scale ? fr29_twiddle_from(*scale) : Fr29{};
+    Fr29 sc_up = scale_upper ? fr29_twiddle_from(*scale_upper) : Fr29{};
+    const int scale_mode = scale_upper ? 2 : 1;
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS
@@ -407,10 +461,10 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
         if (dif) {
             hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
-                               tpb_log, tw, n, sc, (last && scale) ? 1 : 0, last ? 1 : 0);
+                               tpb_log, tw, n, sc, sc_up, (last && scale) ? scale_mode : 0, last ? 1 : 0);
         } else {
             hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
-                               tpb_log, tw, n, sc, (last && scale) ? 1 : 0, last ? 1 : 0);
+                               tpb_log, tw, n, sc, sc_up, (last && scale) ? scale_mode : 0, last ? 1 : 0);
         }
     }
     return PLONK_HIP_OK;
@@ -440,16 +494,6 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
 // ------------------------------------------------------------------------------------------
 // coset quotient by X^k - 1
 // ------------------------------------------------------------------------------------------
-// Evaluations on the coset g*<omega_2k> in bit-reversed order: position p holds the point
-// g * omega^rev(p); (g omega^e)^k - 1 = g^k (-1)^e - 1 and e is even exactly when p < k.
-__global__ __launch_bounds__(256) void k_mul_halves(Fr *__restrict__ data, size_t n, size_t batch_stride, Fr lo_half,
-                                                   Fr hi_half) {
-    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    Fr *q = data + (size_t)blockIdx.y * batch_stride + p;
-    *q = fe_mul(*q, p < n / 2 ? lo_half : hi_half);
-}
-
 __global__ void k_set_int(int *__restrict__ flags, size_t count, int value) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) flags[i] = value;
@@ -479,9 +523,8 @@ int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch
     Fr inv_even = fe_inv(z_even), inv_odd = fe_inv(z_odd);
 
     PLONK_TRY(scale_by_powers(ctx, d_f, n, batch, g));
-    PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, nullptr));
-    hipLaunchKernelGGL(k_mul_halves, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_f, n, n,
-                       inv_even, inv_odd);
+    // 1/Z rides on the store of the last butterfly pass
+    PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd));
     Fr ninv = fe_inv(fr_from_u64(n));
     PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv));
     PLONK_TRY(scale_by_powers(ctx, d_f, n, batch, fe_inv(g)));
