@@ -182,6 +182,45 @@ int plonk_hip_fr_quotient_coset(plonk_hip_ctx *ctx, const uint64_t *f, uint32_t 
 int plonk_hip_fr_quotient_coset_dev(plonk_hip_ctx *ctx, void *d_f_inout, uint32_t log_k, size_t batch,
                                     int *d_divisible);
 
+
+/* out[i] = f(points[i]), i < m: the `f.evaluate(&Omega[j])` calls of the t builders
+ * (protocols.rs:246, 348, 464, 577-579) for any point set, e.g. an Omega whose size is not a
+ * power of two. */
+int plonk_hip_fr_eval_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *points, size_t m,
+                           uint64_t *out /* m x 4 */);
+/* out[j] = f(omega^j), j < k = 2^log_k, for a polynomial of any length n (it is first reduced
+ * modulo X^k - 1, which keeps its values on Omega). */
+int plonk_hip_fr_evaluate_over_omega(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, uint32_t log_k,
+                                     uint64_t *out /* k x 4 */);
+/* data[i] <- data[0] * ... * data[i]  (the `.reduce(|t_eval, f_eval| t_eval * f_eval)` of
+ * protocols.rs:243-250, computed once instead of per i) and the additive form (protocols.rs:461-468). */
+int plonk_hip_fr_prefix_product(plonk_hip_ctx *ctx, uint64_t *data, size_t n);
+int plonk_hip_fr_prefix_sum(plonk_hip_ctx *ctx, uint64_t *data, size_t n);
+/* data[i] <- 1 / data[i]; PLONK_HIP_ERR_ZERO_DENOMINATOR if some element is zero (data is then
+ * unspecified), where the reference panics on `.inverse().unwrap()` (protocols.rs:349, 583). */
+int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n);
+/* out[i] = prod_{j<=i} num[j] / den[j]: the t values of the rational product check and of the
+ * prescribed-permutation check (protocols.rs:345-353, 571-588). */
+int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, const uint64_t *den, size_t n,
+                                      uint64_t *out /* n x 4 */);
+/* Dense product `&a * &b` (protocols.rs:272, 382, 490, 635, 749; prover/part3.rs:59):
+ * na + nb - 1 coefficients, untrimmed.  Nothing is written when na or nb is 0. */
+int plonk_hip_fr_poly_mul(plonk_hip_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb,
+                          uint64_t *out);
+/* `construct_vanishing_polynomial_from_roots(roots)` (plonk/src/common/utils.rs:51-62):
+ * prod (X - roots[i]), m + 1 coefficients. */
+int plonk_hip_fr_vanishing_from_roots(plonk_hip_ctx *ctx, const uint64_t *roots, size_t m, uint64_t *z);
+/* `compute_q_zero_test_from_roots(roots, f)` (protocols.rs:169-181): quotient of f (n coefficients)
+ * by prod (X - roots[i]) with the remainder dropped; q receives n - m coefficients (n > m),
+ * untrimmed. */
+int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, const uint64_t *roots, size_t m,
+                              uint64_t *q);
+/* `interpolate_polynomial(xs, ys)` (plonk/src/common/polynomials.rs:14-58) for arbitrary points:
+ * n coefficients, untrimmed.  Quadratic work, n <= 65536 (use plonk_hip_fr_ntt with inverse = 1 when
+ * xs = Omega).  PLONK_HIP_ERR_ZERO_DENOMINATOR when two xs coincide (the reference panics,
+ * polynomials.rs:42). */
+int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *coeffs);
+
 #ifdef __cplusplus
 }
 #endif

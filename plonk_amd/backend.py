@@ -259,6 +259,80 @@ class Backend:
             self._check(self._lib.plonk_hip_fr_div_vanishing(self._ctx, _u64(f), n, k, _u64(q)))
         return q
 
+    def fr_eval_many(self, coeffs, points):
+        """f(points[i]) for every i: the `f.evaluate(&Omega[j])` calls of protocols.rs:246, 348, 464, 577."""
+        coeffs, points = _fr(coeffs), _fr(points)
+        out = np.empty((points.shape[0], 4), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_eval_many(self._ctx, _u64(coeffs), coeffs.shape[0], _u64(points),
+                                                     points.shape[0], _u64(out)))
+        return out
+
+    def fr_evaluate_over_omega(self, coeffs, log_k):
+        """f(omega^j), j < 2^log_k, for a polynomial of any length."""
+        coeffs = _fr(coeffs)
+        out = np.empty((1 << log_k, 4), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_evaluate_over_omega(self._ctx, _u64(coeffs), coeffs.shape[0], log_k,
+                                                               _u64(out)))
+        return out
+
+    def fr_prefix_product(self, data):
+        d = np.array(_fr(data), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_prefix_product(self._ctx, _u64(d), d.shape[0]))
+        return d
+
+    def fr_prefix_sum(self, data):
+        d = np.array(_fr(data), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_prefix_sum(self._ctx, _u64(d), d.shape[0]))
+        return d
+
+    def fr_batch_inverse(self, data):
+        """Element-wise inverse; raises ReferencePanic on a zero element (`inverse().unwrap()`)."""
+        d = np.array(_fr(data), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_batch_inverse(self._ctx, _u64(d), d.shape[0]))
+        return d
+
+    def fr_ratio_prefix_product(self, num, den):
+        """t_i = prod_{j<=i} num_j / den_j (protocols.rs:345-353, 571-588)."""
+        num, den = _fr(num), _fr(den)
+        assert num.shape == den.shape
+        out = np.empty_like(num)
+        self._check(self._lib.plonk_hip_fr_ratio_prefix_product(self._ctx, _u64(num), _u64(den), num.shape[0],
+                                                                _u64(out)))
+        return out
+
+    def fr_poly_mul(self, a, b):
+        """Dense product `&a * &b`, untrimmed (empty when either factor is empty)."""
+        a, b = _fr(a), _fr(b)
+        na, nb = a.shape[0], b.shape[0]
+        out = np.zeros((na + nb - 1 if na and nb else 0, 4), dtype=np.uint64)
+        if na and nb:
+            self._check(self._lib.plonk_hip_fr_poly_mul(self._ctx, _u64(a), na, _u64(b), nb, _u64(out)))
+        return out
+
+    def construct_vanishing_polynomial_from_roots(self, roots):
+        """prod (X - root_i) (utils.rs:51-62)."""
+        roots = _fr(roots)
+        z = np.empty((roots.shape[0] + 1, 4), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_vanishing_from_roots(self._ctx, _u64(roots), roots.shape[0], _u64(z)))
+        return z
+
+    def compute_q_zero_test_from_roots(self, roots, f):
+        """`compute_q_zero_test_from_roots(roots, f)` (protocols.rs:169-181), untrimmed."""
+        roots, f = _fr(roots), _fr(f)
+        n, m = f.shape[0], roots.shape[0]
+        q = np.zeros((max(n - m, 0), 4), dtype=np.uint64)
+        if n > m:
+            self._check(self._lib.plonk_hip_fr_div_by_roots(self._ctx, _u64(f), n, _u64(roots), m, _u64(q)))
+        return q
+
+    def interpolate_polynomial(self, xs, ys):
+        """`interpolate_polynomial(xs, ys)` (polynomials.rs:50-58) at arbitrary points, untrimmed."""
+        xs, ys = _fr(xs), _fr(ys)
+        assert xs.shape == ys.shape
+        out = np.empty_like(xs)
+        self._check(self._lib.plonk_hip_fr_interpolate(self._ctx, _u64(xs), _u64(ys), xs.shape[0], _u64(out)))
+        return out
+
     def quotient_coset(self, f):
         """Batch of polynomials with 2k coefficients each -> (q (batch, k, 4), divisible flags)."""
         f = np.ascontiguousarray(f, dtype=np.uint64)

@@ -76,7 +76,8 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
                       &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
-                      &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b};
+                      &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b,
+                      &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
         for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
@@ -404,6 +405,163 @@ int plonk_hip_fr_quotient_coset(plonk_hip_ctx *ctx, const uint64_t *f, uint32_t 
     }
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
+}
+
+
+// ---------------------------------------------------------------------------- polynomial building blocks
+// a zeroed int in device memory for the kernels' "zero denominator" report
+static int fresh_flag(plonk_hip_ctx *ctx, int **d_flag) {
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    *d_flag = (int *)((char *)ctx->out_stage.ptr + 64 * sizeof(G1Jac));
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(*d_flag, 0, sizeof(int), ctx->stream));
+    return PLONK_HIP_OK;
+}
+static int read_flag(plonk_hip_ctx *ctx, const int *d_flag, int *out) {
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(out, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+static int upload(plonk_hip_ctx *ctx, DevBuf &buf, const uint64_t *src, size_t elems, size_t reserve_elems, Fr **d) {
+    PLONK_TRY(buf_reserve(ctx, buf, (reserve_elems > elems ? reserve_elems : elems) * sizeof(Fr)));
+    *d = (Fr *)buf.ptr;
+    if (elems) PLONK_HIP_TRY(ctx, hipMemcpyAsync(*d, src, elems * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    return PLONK_HIP_OK;
+}
+static int download(plonk_hip_ctx *ctx, uint64_t *dst, const Fr *d, size_t elems) {
+    if (elems) PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst, d, elems * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_eval_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *points, size_t m,
+                           uint64_t *out) {
+    PLONK_TRY(bind(ctx));
+    if ((!coeffs && n) || ((!points || !out) && m)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (m == 0) return PLONK_HIP_OK;
+    Fr *d_f, *d_p, *d_o;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, coeffs, n, 1, &d_f));
+    PLONK_TRY(upload(ctx, ctx->scratch_c, points, m, 0, &d_p));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, m * sizeof(Fr)));
+    d_o = (Fr *)ctx->stage_c.ptr;
+    PLONK_TRY(eval_points(ctx, d_f, n, d_p, m, d_o));
+    return download(ctx, out, d_o, m);
+}
+
+int plonk_hip_fr_evaluate_over_omega(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, uint32_t log_k,
+                                     uint64_t *out) {
+    PLONK_TRY(bind(ctx));
+    if ((!coeffs && n) || !out || log_k > 30) return PLONK_HIP_ERR_INVALID_ARG;
+    const size_t k = (size_t)1 << log_k;
+    Fr *d_f, *d_o;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, coeffs, n, 1, &d_f));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, k * sizeof(Fr)));
+    d_o = (Fr *)ctx->scratch_c.ptr;
+    PLONK_TRY(fold_mod_vanishing(ctx, d_f, n, k, d_o));
+    PLONK_TRY(ntt_dev(ctx, d_o, log_k, 1, false, nullptr));
+    return download(ctx, out, d_o, k);
+}
+
+static int prefix_host(plonk_hip_ctx *ctx, uint64_t *data, size_t n, bool product) {
+    PLONK_TRY(bind(ctx));
+    if (!data && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    Fr *d;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, data, n, n + prefix_scan_scratch_elems(n), &d));
+    PLONK_TRY(prefix_scan(ctx, d, n, product, d + n));
+    return download(ctx, data, d, n);
+}
+int plonk_hip_fr_prefix_product(plonk_hip_ctx *ctx, uint64_t *data, size_t n) { return prefix_host(ctx, data, n, true); }
+int plonk_hip_fr_prefix_sum(plonk_hip_ctx *ctx, uint64_t *data, size_t n) { return prefix_host(ctx, data, n, false); }
+
+int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n) {
+    PLONK_TRY(bind(ctx));
+    if (!data && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    Fr *d;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, data, n, 0, &d));
+    PLONK_TRY(batch_inverse(ctx, d, n, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    if (flag) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
+    return download(ctx, data, d, n);
+}
+
+int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, const uint64_t *den, size_t n,
+                                      uint64_t *out) {
+    PLONK_TRY(bind(ctx));
+    if ((!num || !den || !out) && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    Fr *d_num, *d_den;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, num, n, n + prefix_scan_scratch_elems(n), &d_num));
+    PLONK_TRY(upload(ctx, ctx->scratch_c, den, n, 0, &d_den));
+    PLONK_TRY(batch_inverse(ctx, d_den, n, d_flag));
+    PLONK_TRY(pointwise_mul(ctx, d_num, d_den, d_num, n));
+    PLONK_TRY(prefix_scan(ctx, d_num, n, true, d_num + n));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    if (flag) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
+    return download(ctx, out, d_num, n);
+}
+
+int plonk_hip_fr_poly_mul(plonk_hip_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb,
+                          uint64_t *out) {
+    PLONK_TRY(bind(ctx));
+    if ((!a && na) || (!b && nb)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (na == 0 || nb == 0) return PLONK_HIP_OK;
+    if (!out) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr *d_a, *d_b;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, a, na, 0, &d_a));
+    PLONK_TRY(upload(ctx, ctx->scratch_c, b, nb, 0, &d_b));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, (na + nb - 1) * sizeof(Fr)));
+    Fr *d_o = (Fr *)ctx->stage_c.ptr;
+    PLONK_TRY(poly_mul_dev(ctx, d_a, na, d_b, nb, d_o, na + nb - 1));
+    return download(ctx, out, d_o, na + nb - 1);
+}
+
+int plonk_hip_fr_vanishing_from_roots(plonk_hip_ctx *ctx, const uint64_t *roots, size_t m, uint64_t *z) {
+    PLONK_TRY(bind(ctx));
+    if ((!roots && m) || !z) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr *d_r;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, roots, m, 1, &d_r));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (m + 1) * sizeof(Fr)));
+    Fr *d_z = (Fr *)ctx->scratch_c.ptr;
+    PLONK_TRY(vanishing_from_roots_dev(ctx, d_r, m, d_z));
+    return download(ctx, z, d_z, m + 1);
+}
+
+int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, const uint64_t *roots, size_t m,
+                              uint64_t *q) {
+    PLONK_TRY(bind(ctx));
+    if ((!f && n) || (!roots && m)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n <= m) return PLONK_HIP_OK;
+    if (!q) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr *d_f, *d_r;
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, f, n, 0, &d_f));
+    PLONK_TRY(upload(ctx, ctx->scratch_c, roots, m, 1, &d_r));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, (n - m) * sizeof(Fr)));
+    Fr *d_q = (Fr *)ctx->stage_c.ptr;
+    PLONK_TRY(div_by_roots_dev(ctx, d_f, n, d_r, (const Fr *)roots, m, d_q));
+    return download(ctx, q, d_q, n - m);
+}
+
+int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *coeffs) {
+    PLONK_TRY(bind(ctx));
+    if ((!xs || !ys || !coeffs) && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    if (n > kMaxInterpolationPoints) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr *d_x, *d_y;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, xs, n, 0, &d_x));
+    PLONK_TRY(upload(ctx, ctx->scratch_c, ys, n, 0, &d_y));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, n * sizeof(Fr)));
+    Fr *d_o = (Fr *)ctx->stage_c.ptr;
+    PLONK_TRY(interpolate_dev(ctx, d_x, d_y, n, d_o, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    if (flag) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
+    return download(ctx, coeffs, d_o, n);
 }
 
 }  // extern "C"

@@ -43,9 +43,11 @@ struct plonk_hip_ctx {
     // MSM workspace
     plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
     plonk::DevBuf bucket_start, buckets, seg_part, big_list, red_a, red_b, red_lw, red_sum_a, red_sum_b;
-    plonk::DevBuf scalars_stage, out_stage;
+    plonk::DevBuf scalars_stage, out_stage, stage_c;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
+    // workspaces of the polynomial product, product tree, series division and interpolation
+    plonk::DevBuf mul_ws, tree_ws, div_ws, interp_ws;
     // two levels of the SRS in 12 x 32-bit affine form while the window tables are being built
     plonk::DevBuf level_a, level_b;
     // fixed-base table of the generator for kzg_setup (32 windows x 256 affine multiples)

@@ -470,6 +470,23 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     return PLONK_HIP_OK;
 }
 
+int ntt_butterflies(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse) {
+    if (log_n > 30) return PLONK_HIP_ERR_INVALID_ARG;
+    if (batch == 0 || log_n == 0) return PLONK_HIP_OK;
+    const size_t n = (size_t)1 << log_n;
+    const Fr ninv = fe_inv(fr_from_u64(n));
+    // the batch index is a grid dimension: long batches go in slabs
+    for (size_t b0 = 0; b0 < batch; b0 += 32768) {
+        size_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
+        if (inverse) {
+            PLONK_TRY(run_passes(ctx, d_data + b0 * n, log_n, nb, true, false, &ninv));
+        } else {
+            PLONK_TRY(run_passes(ctx, d_data + b0 * n, log_n, nb, false, true, nullptr));
+        }
+    }
+    return PLONK_HIP_OK;
+}
+
 int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse, const Fr *coset_shift) {
     if (log_n > 30 || batch > 65535) return PLONK_HIP_ERR_INVALID_ARG;
     if (batch == 0 || log_n == 0) return PLONK_HIP_OK;  // one point: f(shift * 1) = f_0 either way

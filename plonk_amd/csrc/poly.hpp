@@ -12,7 +12,34 @@ int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, cons
 // q[j] = sum_{m>=1} f[j + m*k], j < n - k.
 int div_vanishing(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, size_t k, Fr *d_q);
 
+// polyops.hip
+// inclusive running product (or sum) in place; scratch must hold prefix_scan_scratch_elems(n) elements
+size_t prefix_scan_scratch_elems(size_t n);
+int prefix_scan(plonk_hip_ctx *ctx, Fr *d, size_t n, bool product, Fr *d_scratch);
+// element-wise inverse in place; *d_flag (device int, cleared by the caller) becomes 1 on a zero element
+int batch_inverse(plonk_hip_ctx *ctx, Fr *d, size_t n, int *d_flag);
+int pointwise_mul(plonk_hip_ctx *ctx, const Fr *a, const Fr *b, Fr *out, size_t count);
+// out[j] = sum_t f[j + t*k], j < k
+int fold_mod_vanishing(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, size_t k, Fr *d_out);
+// out[i] = f(points[i])
+int eval_points(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const Fr *d_pts, size_t m, Fr *d_out);
+// first `keep` coefficients of a*b
+int poly_mul_dev(plonk_hip_ctx *ctx, const Fr *d_a, size_t na, const Fr *d_b, size_t nb, Fr *d_out, size_t keep);
+// prod (X - roots[i]): m + 1 coefficients
+int vanishing_from_roots_dev(plonk_hip_ctx *ctx, const Fr *d_roots, size_t m, Fr *d_z);
+// floor(f / z), z monic of degree m: n - m coefficients
+int poly_div_monic_dev(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const Fr *d_z, size_t m, Fr *d_q);
+// floor(f / prod (X - roots[i])); the roots are given both in device and in host memory
+int div_by_roots_dev(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const Fr *d_roots, const Fr *h_roots, size_t m,
+                     Fr *d_q);
+// interpolation at arbitrary points (quadratic work)
+static constexpr size_t kMaxInterpolationPoints = (size_t)1 << 16;
+int interpolate_dev(plonk_hip_ctx *ctx, const Fr *d_x, const Fr *d_y, size_t n, Fr *d_out, int *d_flag);
+
 // ntt.hip
+// butterflies only: forward = natural order in, bit-reversed order out, no scaling;
+// inverse = bit-reversed in, natural out, scaled by 1/n
+int ntt_butterflies(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse);
 int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse, const Fr *coset_shift);
 int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch, int *d_divisible);
 

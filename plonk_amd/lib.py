@@ -63,6 +63,19 @@ SIGNATURES = {
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint32, ctypes.c_size_t, c_u64p, c_intp]),
     "plonk_hip_fr_quotient_coset_dev": (
         ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, c_intp]),
+    "plonk_hip_fr_eval_many": (
+        ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_evaluate_over_omega": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_uint32, c_u64p]),
+    "plonk_hip_fr_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
+    "plonk_hip_fr_prefix_sum": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
+    "plonk_hip_fr_batch_inverse": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
+    "plonk_hip_fr_ratio_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_poly_mul": (
+        ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_vanishing_from_roots": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_div_by_roots": (
+        ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_interpolate": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
 }
 
 _lib = None
