@@ -28,6 +28,21 @@ import numpy as np
 # Algorithmic work per MSM point: 16 signed 16-bit windows x one mixed addition (8M + 2S = 10 Fq
 # multiplications) x 300 32-bit multiply-adds per 12-limb Montgomery multiplication.
 MADS_PER_POINT = 16 * 10 * 300
+# k_accumulate, 2^24 points on one GPU: 2 x FETCH_SIZE (gfx950 counts 128-byte requests as 64 bytes;
+# checked on the gather microbenchmark) + WRITE_SIZE, averaged over the launches of one bench run
+PMC_TRAFFIC_BYTES = int((2 * 52582390 + 7018503) * 1024)
+
+
+def hbm_view(be, n_local, windows, acc_ms):
+    """Memory side of k_accumulate: one 128-byte table line plus one sorted (bucket, entry) pair per
+    point and window, against the HBM peak and against the measured random-line gather rate for a
+    table of this size."""
+    bytes_per_launch = n_local * windows * (128 + 8)
+    achieved = bytes_per_launch / (acc_ms * 1e-3) / 1e9
+    gather = be.bench_gather_rate(min(n_local * windows * 128, 48 << 30)) / 1e9
+    return {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_launch": bytes_per_launch,
+            "random_line_gather_ceiling": round(gather, 1), "frac_of_gather_ceiling": round(achieved / gather, 3)}
 BYTES_PER_POINT = 96 + 32  # affine point + scalar
 FR_MADS_PER_MUL = 136
 HBM_PEAK_GBS = 8000.0
@@ -229,16 +244,14 @@ def main():
                 "peak": round(peak / 1e12, 3),
                 "unit": "Tmad/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_BYTES if (args.log_n == 24 and world == 1) else None,
                 "note": "algorithmic 48000 multiply-adds per point (16 windows x 10 Fq mul x 300) x points per "
                         "launch / average k_accumulate duration (HIP events on the library stream); peak = "
-                        "v_mad_u64_u32 register-only microbenchmark run in this process",
+                        "v_mad_u64_u32 register-only microbenchmark run in this process; traffic = bytes per "
+                        "launch from the committed rocprofv3 counter pass (2 x FETCH_SIZE + WRITE_SIZE, "
+                        "profiles/r01_b_pmc_per_kernel.csv)",
                 "kernel_ms": round(acc_ms, 3),
-                "hbm_view": {
-                    "achieved": round(BYTES_PER_POINT * n_local / (acc_ms * 1e-3) / 1e9, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(BYTES_PER_POINT * n_local / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                },
+                "hbm_view": hbm_view(be, n_local, plan["windows"], acc_ms),
             },
             "msm_phase_ms": phase_avg,
         }

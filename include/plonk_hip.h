@@ -18,8 +18,10 @@
  * Unless a name ends in `_dev`, pointers are HOST pointers, calls are synchronous and results
  * are valid on return.  `_dev` entry points take DEVICE pointers (memory of the context's GPU),
  * enqueue on the context's stream and return without waiting; call plonk_hip_sync().
- * A context is bound to one GPU; calls on one context must not overlap (serialise them or use
- * one context per thread).  All entry points return 0 on success or a negative PLONK_HIP_ERR_*.
+ * A context is bound to one GPU.  Entry points may be called from any thread: calls on one
+ * context are serialised by a lock inside it (`_dev` calls only enqueue, so two threads sharing
+ * a context still share its stream order); use one context per thread for concurrency.
+ * All entry points return 0 on success or a negative PLONK_HIP_ERR_*.
  * Nothing unwinds across this boundary.
  */
 #ifndef PLONK_HIP_H
@@ -140,6 +142,9 @@ int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, do
  * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
 int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
 /* Window plan in force: bits per window, windows, buckets. */
+/* Measured bytes/s of a random gather of whole 128-byte lines from a table of table_bytes: the
+ * memory-side ceiling of the bucket accumulation's table reads. */
+int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
 
 /* ----------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 // C ABI of libplonk_hip (see include/plonk_hip.h for the contract of every entry point).
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "context.hpp"
@@ -34,10 +35,16 @@ void buf_release(DevBuf &b) {
 }  // namespace plonk
 
 static int bind(plonk_hip_ctx *ctx) {
-    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
     PLONK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return PLONK_HIP_OK;
 }
+
+// Every entry point that touches the GPU holds the context's lock for its whole duration and
+// makes the context's device current on the calling thread.
+#define PLONK_ENTER(ctx)                                        \
+    if (!(ctx)) return PLONK_HIP_ERR_INVALID_ARG;               \
+    std::lock_guard<std::recursive_mutex> _plonk_guard((ctx)->mu); \
+    PLONK_TRY(bind(ctx))
 
 static Fr load_fr(const uint64_t v[4]) {
     Fr r;
@@ -114,34 +121,34 @@ int plonk_hip_ctx_set_window_bits(plonk_hip_ctx *ctx, int c) {
 void *plonk_hip_ctx_stream(plonk_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int plonk_hip_sync(plonk_hip_ctx *ctx) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
 }
 
 int plonk_hip_malloc(plonk_hip_ctx *ctx, size_t bytes, void **dptr) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!dptr) return PLONK_HIP_ERR_INVALID_ARG;
     PLONK_HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
     return PLONK_HIP_OK;
 }
 
 int plonk_hip_free(plonk_hip_ctx *ctx, void *dptr) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     PLONK_HIP_TRY(ctx, hipFree(dptr));
     return PLONK_HIP_OK;
 }
 
 int plonk_hip_memcpy_h2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
 }
 
 int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
@@ -149,7 +156,7 @@ int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev
 
 // ---------------------------------------------------------------------------- SRS
 int plonk_hip_srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     return srs_load_projective(ctx, pts, n);
 }
 
@@ -160,36 +167,36 @@ int plonk_hip_srs_size(plonk_hip_ctx *ctx, size_t *n) {
 }
 
 int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     return srs_read(ctx, first, count, out);
 }
 
 int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     return srs_setup(ctx, tau, 0, degree + 1, out_pts);
 }
 
 int plonk_hip_kzg_setup_range(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t count,
                               uint64_t *out_pts) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     return srs_setup(ctx, tau, first, count, out_pts);
 }
 
 int plonk_hip_g1_sum_dev(plonk_hip_ctx *ctx, const void *d_pts, size_t n, void *d_out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!d_pts || !d_out) return PLONK_HIP_ERR_INVALID_ARG;
     return g1_sum_dev(ctx, (const G1Jac *)d_pts, n, (G1Jac *)d_out);
 }
 
 // ---------------------------------------------------------------------------- commit / open
 int plonk_hip_kzg_commit_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!d_coeffs || !d_out) return PLONK_HIP_ERR_INVALID_ARG;
     return msm_run_dev(ctx, (const Fr *)d_coeffs, n, (G1Jac *)d_out);
 }
 
 int plonk_hip_kzg_commit(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t out[18]) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!out || (!coeffs && n)) return PLONK_HIP_ERR_INVALID_ARG;
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
@@ -206,14 +213,40 @@ int plonk_hip_kzg_commit(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, u
 
 int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
                                uint64_t *outs) {
+    PLONK_ENTER(ctx);
     if (!coeffs || !ns || !outs) return PLONK_HIP_ERR_INVALID_ARG;
-    for (size_t b = 0; b < batch; b++) PLONK_TRY(plonk_hip_kzg_commit(ctx, coeffs[b], ns[b], outs + 18 * b));
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    size_t total = 0;
+    for (size_t b = 0; b < batch; b++) {
+        if (ns[b] == 0 || !coeffs[b]) return PLONK_HIP_ERR_EMPTY_POLY;
+        if (ns[b] > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+        total += ns[b];
+    }
+    if (batch == 0) return PLONK_HIP_OK;
+    // all coefficient vectors are staged back to back, the commitments are queued one after the
+    // other on the stream, and the host waits once for the whole group
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, total * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, batch * sizeof(G1Jac)));
+    Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
+    G1Jac *d_out = (G1Jac *)ctx->stage_c.ptr;
+    size_t off = 0;
+    for (size_t b = 0; b < batch; b++) {
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f + off, coeffs[b], ns[b] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        off += ns[b];
+    }
+    off = 0;
+    for (size_t b = 0; b < batch; b++) {
+        PLONK_TRY(msm_run_dev(ctx, d_f + off, ns[b], d_out + b));
+        off += ns[b];
+    }
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
 }
 
 int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
                             uint64_t *vs, uint64_t *proofs) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!coeffs || !us || !vs || !proofs) return PLONK_HIP_ERR_INVALID_ARG;
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
@@ -244,22 +277,28 @@ int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, con
 }
 
 int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!mads_per_second) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_mad_rate(ctx, mads_per_second);
 }
 
 int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!muls_per_second || blocks_per_cu < 1) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_fq_mul_rate(ctx, variant, blocks_per_cu, muls_per_second);
 }
 
 int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second,
                              double *clock_ghz) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!mads_per_second || !clock_ghz || blocks_per_cu < 1) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_mad_mix(ctx, extra, blocks_per_cu, mads_per_second, clock_ghz);
+}
+
+int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
+    PLONK_ENTER(ctx);
+    if (!bytes_per_second) return PLONK_HIP_ERR_INVALID_ARG;
+    return bench_gather_rate(ctx, table_bytes, bytes_per_second);
 }
 
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {
@@ -269,7 +308,7 @@ int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {
 }
 
 int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!ms || !ctx->profile) return PLONK_HIP_ERR_INVALID_ARG;
     PLONK_HIP_TRY(ctx, hipEventSynchronize(ctx->ev[PH_COUNT]));
     for (int i = 0; i < PH_COUNT; i++) PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
@@ -292,7 +331,7 @@ int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_
 
 // ---------------------------------------------------------------------------- polynomials
 int plonk_hip_fr_scale_by_powers(plonk_hip_ctx *ctx, uint64_t *coeffs, size_t n, const uint64_t w[4]) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!coeffs && n) || !w) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) return PLONK_HIP_OK;
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * sizeof(Fr)));
@@ -305,7 +344,7 @@ int plonk_hip_fr_scale_by_powers(plonk_hip_ctx *ctx, uint64_t *coeffs, size_t n,
 }
 
 int plonk_hip_fr_eval(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t out[4]) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!coeffs && n) || !u || !out) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) {
         memset(out, 0, 32);  // the zero polynomial evaluates to zero
@@ -324,7 +363,7 @@ int plonk_hip_fr_eval(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, cons
 }
 
 int plonk_hip_fr_div_vanishing(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, size_t k, uint64_t *q) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!f || !q || k == 0) return PLONK_HIP_ERR_INVALID_ARG;
     if (n <= k) return PLONK_HIP_OK;
     PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
@@ -340,7 +379,7 @@ int plonk_hip_fr_div_vanishing(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, 
 
 static int ntt_host(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, const uint64_t *shift,
                     int inverse) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!data || log_n > 30) return PLONK_HIP_ERR_INVALID_ARG;
     size_t total = ((size_t)1 << log_n) * batch;
     if (total == 0) return PLONK_HIP_OK;
@@ -366,14 +405,14 @@ int plonk_hip_fr_coset_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, s
 }
 
 int plonk_hip_fr_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch, int inverse) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!d_data) return PLONK_HIP_ERR_INVALID_ARG;
     return ntt_dev(ctx, (Fr *)d_data, log_n, batch, inverse != 0, nullptr);
 }
 
 int plonk_hip_fr_coset_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch,
                                const uint64_t shift[4], int inverse) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!d_data || !shift) return PLONK_HIP_ERR_INVALID_ARG;
     Fr sh = load_fr(shift);
     return ntt_dev(ctx, (Fr *)d_data, log_n, batch, inverse != 0, &sh);
@@ -381,14 +420,14 @@ int plonk_hip_fr_coset_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n,
 
 int plonk_hip_fr_quotient_coset_dev(plonk_hip_ctx *ctx, void *d_f_inout, uint32_t log_k, size_t batch,
                                     int *d_divisible) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!d_f_inout) return PLONK_HIP_ERR_INVALID_ARG;
     return quotient_coset_dev(ctx, (Fr *)d_f_inout, log_k, batch, d_divisible);
 }
 
 int plonk_hip_fr_quotient_coset(plonk_hip_ctx *ctx, const uint64_t *f, uint32_t log_k, size_t batch, uint64_t *q,
                                 int *divisible) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!f || !q || log_k > 29) return PLONK_HIP_ERR_INVALID_ARG;
     if (batch == 0) return PLONK_HIP_OK;
     const size_t k = (size_t)1 << log_k, n = 2 * k;
@@ -435,7 +474,7 @@ static int download(plonk_hip_ctx *ctx, uint64_t *dst, const Fr *d, size_t elems
 
 int plonk_hip_fr_eval_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *points, size_t m,
                            uint64_t *out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!coeffs && n) || ((!points || !out) && m)) return PLONK_HIP_ERR_INVALID_ARG;
     if (m == 0) return PLONK_HIP_OK;
     Fr *d_f, *d_p, *d_o;
@@ -449,7 +488,7 @@ int plonk_hip_fr_eval_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n,
 
 int plonk_hip_fr_evaluate_over_omega(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, uint32_t log_k,
                                      uint64_t *out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!coeffs && n) || !out || log_k > 30) return PLONK_HIP_ERR_INVALID_ARG;
     const size_t k = (size_t)1 << log_k;
     Fr *d_f, *d_o;
@@ -462,7 +501,7 @@ int plonk_hip_fr_evaluate_over_omega(plonk_hip_ctx *ctx, const uint64_t *coeffs,
 }
 
 static int prefix_host(plonk_hip_ctx *ctx, uint64_t *data, size_t n, bool product) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!data && n) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) return PLONK_HIP_OK;
     Fr *d;
@@ -474,7 +513,7 @@ int plonk_hip_fr_prefix_product(plonk_hip_ctx *ctx, uint64_t *data, size_t n) { 
 int plonk_hip_fr_prefix_sum(plonk_hip_ctx *ctx, uint64_t *data, size_t n) { return prefix_host(ctx, data, n, false); }
 
 int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if (!data && n) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) return PLONK_HIP_OK;
     Fr *d;
@@ -489,7 +528,7 @@ int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n) {
 
 int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, const uint64_t *den, size_t n,
                                       uint64_t *out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!num || !den || !out) && n) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) return PLONK_HIP_OK;
     Fr *d_num, *d_den;
@@ -507,7 +546,7 @@ int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, c
 
 int plonk_hip_fr_poly_mul(plonk_hip_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb,
                           uint64_t *out) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!a && na) || (!b && nb)) return PLONK_HIP_ERR_INVALID_ARG;
     if (na == 0 || nb == 0) return PLONK_HIP_OK;
     if (!out) return PLONK_HIP_ERR_INVALID_ARG;
@@ -521,7 +560,7 @@ int plonk_hip_fr_poly_mul(plonk_hip_ctx *ctx, const uint64_t *a, size_t na, cons
 }
 
 int plonk_hip_fr_vanishing_from_roots(plonk_hip_ctx *ctx, const uint64_t *roots, size_t m, uint64_t *z) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!roots && m) || !z) return PLONK_HIP_ERR_INVALID_ARG;
     Fr *d_r;
     PLONK_TRY(upload(ctx, ctx->scalars_stage, roots, m, 1, &d_r));
@@ -533,7 +572,7 @@ int plonk_hip_fr_vanishing_from_roots(plonk_hip_ctx *ctx, const uint64_t *roots,
 
 int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, const uint64_t *roots, size_t m,
                               uint64_t *q) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!f && n) || (!roots && m)) return PLONK_HIP_ERR_INVALID_ARG;
     if (n <= m) return PLONK_HIP_OK;
     if (!q) return PLONK_HIP_ERR_INVALID_ARG;
@@ -547,7 +586,7 @@ int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, c
 }
 
 int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *coeffs) {
-    PLONK_TRY(bind(ctx));
+    PLONK_ENTER(ctx);
     if ((!xs || !ys || !coeffs) && n) return PLONK_HIP_ERR_INVALID_ARG;
     if (n == 0) return PLONK_HIP_OK;
     if (n > kMaxInterpolationPoints) return PLONK_HIP_ERR_INVALID_ARG;

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/plonk_hip.h"
@@ -32,6 +33,7 @@ struct plonk_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
+    std::recursive_mutex mu;  // serialises the entry points that use this context
     int window_bits_override = 0;
 
     // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form
@@ -97,6 +99,7 @@ int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, 
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
 int bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second, double *clock_ghz);
 int bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
+int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 
 // srs.hip
 int srs_install_affine(plonk_hip_ctx *ctx, size_t n);  // level 0 already in ctx->table

@@ -201,4 +201,55 @@ int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second) {
     return PLONK_HIP_OK;
 }
 
+// Random 128-byte-line gather: every lane reads `iters` whole lines (8 x 16-byte loads, the access
+// pattern of the bucket accumulation's table reads) at hashed positions of a table of `lines` lines.
+__global__ __launch_bounds__(128) void k_gather_rate(const uint4 *__restrict__ table, uint32_t lines, int iters,
+                                                    uint32_t seed, uint32_t *__restrict__ out) {
+    uint32_t h = seed ^ ((blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < iters; i++) {
+        h = h * 1664525u + 1013904223u;
+        uint32_t line = (uint32_t)(((uint64_t)(h ^ (h >> 15)) * lines) >> 32);
+        const uint4 *p = table + (size_t)line * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint4 v = p[k];
+            acc.x ^= v.x;
+            acc.y += v.y;
+            acc.z ^= v.z;
+            acc.w += v.w;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
+// Bytes per second of that gather over a table of table_bytes (rounded down to whole lines).
+int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
+    const uint32_t lines = (uint32_t)std::min<size_t>(table_bytes / 128, 0x7fffffffu);
+    if (lines == 0) return PLONK_HIP_ERR_INVALID_ARG;
+    const int blocks = 256 * 24, threads = 128, iters = 64;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_a, (size_t)lines * 128));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4));
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch_a.ptr, 1, (size_t)lines * 128, ctx->stream));
+    hipEvent_t e0, e1;
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e0));
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        PLONK_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(k_gather_rate, dim3(blocks), dim3(threads), 0, ctx->stream,
+                           (const uint4 *)ctx->scratch_a.ptr, lines, iters, 0x51ed27u + rep,
+                           (uint32_t *)ctx->scratch_c.ptr);
+        PLONK_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *bytes_per_second = (double)blocks * threads * (double)iters * 128.0 / (best * 1e-3);
+    return PLONK_HIP_OK;
+}
+
 }  // namespace plonk
