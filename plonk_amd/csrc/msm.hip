@@ -108,60 +108,112 @@ __device__ __forceinline__ void flush_run(uint32_t key, uint32_t run_begin, uint
     }
 }
 
+// Whole-line gather through LDS.  A lane reading its own 128-byte table line with eight 16-byte
+// loads makes every wave-load touch 64 different lines; instead the wave fetches its 64 lines with
+// eight loads that each cover eight whole lines (eight lanes per line), written straight into the
+// wave's LDS buffer, and every lane then picks up its own line from there.  Piece s of the line of
+// lane j is stored at slot 8j + (s ^ (j & 7)) so that the read-back spreads over the banks.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+
+__device__ __forceinline__ void issue_lines(const G1Affine28 *__restrict__ table, uint4 *buf, uint32_t lane,
+                                            uint32_t my_index) {
+#pragma unroll
+    for (uint32_t g = 0; g < 8; g++) {
+        const uint32_t owner = 8 * g + (lane >> 3);
+        const uint32_t idx = (uint32_t)__shfl((int)my_index, (int)owner, 64);
+        const uint32_t piece = (lane & 7) ^ (owner & 7);
+        const uint4 *src = reinterpret_cast<const uint4 *>(table + idx) + piece;
+        // destination: wave-uniform base; the hardware adds lane * 16
+        __builtin_amdgcn_global_load_lds((global_void_t *)src, (lds_void_t *)(buf + 64 * g), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ G1Affine28 read_line(const uint4 *buf, uint32_t lane) {
+    G1Affine28 pt;
+    uint4 w[8];
+#pragma unroll
+    for (uint32_t s = 0; s < 8; s++) w[s] = buf[8 * lane + (s ^ (lane & 7))];
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        const uint4 &a = w[i >> 2], &b = w[4 + (i >> 2)];
+        pt.x.l[i] = (i & 3) == 0 ? a.x : (i & 3) == 1 ? a.y : (i & 3) == 2 ? a.z : a.w;
+        pt.y.l[i] = (i & 3) == 0 ? b.x : (i & 3) == 1 ? b.y : (i & 3) == 2 ? b.z : b.w;
+    }
+    return pt;
+}
+
 __global__ __launch_bounds__(kBlock, 3) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                        uint32_t seg_len, const G1Affine28 *__restrict__ table,
                                                        G1Xyzz28 *__restrict__ buckets,
                                                        G1Xyzz28 *__restrict__ part) {
-    size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nvalid = start[nbuckets];
-    size_t begin64 = seg * seg_len;
-    if (begin64 >= nvalid) return;
-    uint32_t begin = (uint32_t)begin64;
-    size_t end64 = begin64 + seg_len;
-    uint32_t end = end64 < nvalid ? (uint32_t)end64 : nvalid;
+    __shared__ uint4 line_buf[kBlock / 64][64 * 8];  // 8 KiB per wave
+    const uint32_t lane = threadIdx.x & 63;
+    uint4 *buf = line_buf[threadIdx.x >> 6];
+    const size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nvalid = start[nbuckets];
+    const size_t begin64 = seg * seg_len;
+    const bool live = begin64 < nvalid;
+    if (__ballot(live) == 0) return;  // the whole wave lies behind the list
+    // lanes without a segment stay in the loop: they carry part of the other lanes' line loads
+    const uint32_t begin = live ? (uint32_t)begin64 : 0u;
+    const size_t end64 = begin64 + seg_len;
+    const uint32_t end = live ? (end64 < nvalid ? (uint32_t)end64 : nvalid) : 0u;
 
-    uint32_t k = keys[begin], v = vals[begin];
+    // (bucket, entry) of the current position and of the next one; the line of the current
+    // position is always on its way to (or in) the wave's buffer
+    uint32_t k = 0, v = 0, kn = 0, vn = 0;
+    if (begin < end) {
+        k = keys[begin];
+        v = vals[begin];
+    }
+    if (begin + 1 < end) {
+        kn = keys[begin + 1];
+        vn = vals[begin + 1];
+    }
+    issue_lines(table, buf, lane, v & 0x7fffffffu);
     uint32_t cur = k;
     uint32_t run_begin = begin;
     G1Xyzz28 acc = xyzz28_identity();
-    for (uint32_t p = begin; p < end; p++) {
-        // (bucket, entry) of the next position, fetched one iteration ahead
-        const bool more = p + 1 < end;
-        uint32_t kn = 0, vn = 0;
-        if (more) {
-            kn = keys[p + 1];
-            vn = vals[p + 1];
+    for (uint32_t it = 0; it < seg_len; it++) {  // the same trip count for every lane of the grid
+        const uint32_t p = begin + it;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this position's lines have landed
+        G1Affine28 pt = read_line(buf, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane holds its line: the buffer is free
+        issue_lines(table, buf, lane, vn & 0x7fffffffu);
+        uint32_t k2 = 0, v2 = 0;
+        if (p + 2 < end) {
+            k2 = keys[p + 2];
+            v2 = vals[p + 2];
         }
-        if (k != cur) {
-            flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
-            cur = k;
-            run_begin = p;
-            acc = xyzz28_identity();
-        }
-        G1Affine28 pt = table[v & 0x7fffffffu];
-        // Pull the next point's 128-byte line towards the L2 while this addition runs: one
-        // dword read whose value is only consumed (by an empty asm) after the addition.
-        uint32_t touch = 0;
-        if (more) touch = table[vn & 0x7fffffffu].x.l[0];
-        if (!affine28_is_identity(pt)) {
-            const bool neg = (v >> 31) != 0;
-            if (xyzz28_is_identity(acc)) {
-                acc.x = pt.x;
-                acc.y = neg ? q28_neg(pt.y) : pt.y;
-                acc.zz = q28_one();
-                acc.zzz = q28_one();
-            } else if (!xyzz28_madd_lazy(acc, pt.x, pt.y, neg)) {
-                G1Xyzz28 t = acc;  // a private copy: acc itself keeps its registers
-                acc = madd_slow_cold(&t, table, v);
+        if (p < end) {
+            if (k != cur) {
+                flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
+                cur = k;
+                run_begin = p;
+                acc = xyzz28_identity();
+            }
+            if (!affine28_is_identity(pt)) {
+                const bool neg = (v >> 31) != 0;
+                if (xyzz28_is_identity(acc)) {
+                    acc.x = pt.x;
+                    acc.y = neg ? q28_neg(pt.y) : pt.y;
+                    acc.zz = q28_one();
+                    acc.zzz = q28_one();
+                } else if (!xyzz28_madd_lazy(acc, pt.x, pt.y, neg)) {
+                    G1Xyzz28 t = acc;  // a private copy: acc itself keeps its registers
+                    acc = madd_slow_cold(&t, table, v);
+                }
             }
         }
-        asm volatile("" ::"v"(touch));
         k = kn;
         v = vn;
+        kn = k2;
+        vn = v2;
     }
-    flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
+    if (live) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
 }
 
 // ------------------------------------------------------------------------------------------
