@@ -238,6 +238,41 @@ PLONK_HD Fq28 q28_mul_lazy(const Fq28 &a, const Fq28 &b) {
     return r;
 }
 
+// (a*b + c*d) / 2^392 mod q with one reduction for both products:
+// a < A*q, b < B*q, c < C*q, d < D*q  =>  result < (1 + (A*B + C*D)/2500) * q.
+// A column holds at most 28 products and 14 reduction terms, each below 2^56: under 2^62.
+PLONK_HD Fq28 q28_mul2_lazy(const Fq28 &a, const Fq28 &b, const Fq28 &c, const Fq28 &d) {
+    constexpr int N = Q28::N;
+    uint64_t acc = 0;
+    uint32_t m[N];
+    Fq28 r;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Q28::mod(k - i);
+        m[k] = ((uint32_t)acc * Q28::INV) & Q28::MASK;
+        acc += (uint64_t)m[k] * Q28::mod(0);
+        acc >>= Q28::BITS;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+            acc += (uint64_t)m[i] * Q28::mod(k - i);
+        }
+        r.l[k - N] = (uint32_t)acc & Q28::MASK;
+        acc >>= Q28::BITS;
+    }
+    return r;
+}
+
 // (sign ? -a : a) - b + K*q in one carry pass.  Needs K*q >= b (+ a when sign is set).
 // Result < a + K*q (sign clear) or <= K*q (sign set).
 template <int K>

@@ -166,11 +166,11 @@ PLONK_HD bool xyzz28_madd_lazy(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2, bo
     PLONK_STEP();
     Fq28 Q = q28_mul_lazy(acc.x, PP);
     PLONK_STEP();
-    Fq28 T = q28_mul_lazy(acc.y, PPP);
-    PLONK_STEP();
     acc.x = q28_sub2_lazy<4>(q28_mul_lazy(R, R), PPP, Q);                 // R^2 - PPP - 2Q  < 5.1 q
     PLONK_STEP();
-    acc.y = q28_sub_lazy<2>(q28_mul_lazy(R, q28_sub_lazy<6>(Q, acc.x)), T);  // R(Q - X3) - T < 3.1 q
+    // Y3 = R (Q - X3) - Y1 PPP as one double-width sum with a single reduction
+    Fq28 negY = q28_sub_lazy<4>(q28_zero(), acc.y);                       // 4q - Y1      <= 4 q
+    acc.y = q28_mul2_lazy(R, q28_sub_lazy<6>(Q, acc.x), negY, PPP);       //              < 1.1 q
     return true;
 }
 
