@@ -30,10 +30,6 @@
 namespace plonk {
 
 static constexpr int kBlock = 128;
-static constexpr int kChunk = 4;       // bucket-reduction chunk (the "4" in the Horner step)
-static constexpr int kChunkLog = 2;
-static constexpr int kMaxLevels = 16;  // 2^(c-1) buckets, c <= 24 -> 12 levels
-static constexpr int kSumBlock = 128;
 
 // Out-of-line doublings: one copy of each per code object.  They are taken only when two equal
 // points meet in one bucket.  Arguments by index / value and results by value, so that no
@@ -238,157 +234,228 @@ __device__ __forceinline__ const G1Xyzz28 *partial_of(const G1Xyzz28 *part, uint
     return part + 2 * s + ((j == 0 && lo != s0 * seg_len) ? 1 : 0);
 }
 
-// One lane per bucket.  Buckets with more than serial_max partials (skewed digit
-// distributions: the narrow top window, repeated scalars) are queued for k_fixup_big.
-__global__ __launch_bounds__(kBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
-                                                  uint32_t seg_len, const G1Xyzz28 *__restrict__ part,
-                                                  G1Xyzz28 *__restrict__ buckets, uint32_t serial_max,
-                                                  uint32_t *__restrict__ big_count,
-                                                  uint32_t *__restrict__ big_list) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    uint32_t lo = start[b], hi = start[b + 1];
-    if (lo == hi) {
-        buckets[b] = xyzz28_identity();
-        return;
+// ---- wave-level sums -----------------------------------------------------------------------
+__device__ __forceinline__ G1Xyzz28 shfl_down_point(const G1Xyzz28 &v, int off, int width) {
+    G1Xyzz28 o;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        o.x.l[i] = (uint32_t)__shfl_down((int)v.x.l[i], off, width);
+        o.y.l[i] = (uint32_t)__shfl_down((int)v.y.l[i], off, width);
+        o.zz.l[i] = (uint32_t)__shfl_down((int)v.zz.l[i], off, width);
+        o.zzz.l[i] = (uint32_t)__shfl_down((int)v.zzz.l[i], off, width);
     }
-    uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
-    if (s0 == s1) {
-        // written whole by k_accumulate, in its lazy form: canonicalise in place
-        buckets[b] = xyzz28_canon(buckets[b]);
-        return;
+    return o;
+}
+__device__ __forceinline__ G1Xyzz28 shfl_point(const G1Xyzz28 &v, int src) {
+    G1Xyzz28 o;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        o.x.l[i] = (uint32_t)__shfl((int)v.x.l[i], src, 64);
+        o.y.l[i] = (uint32_t)__shfl((int)v.y.l[i], src, 64);
+        o.zz.l[i] = (uint32_t)__shfl((int)v.zz.l[i], src, 64);
+        o.zzz.l[i] = (uint32_t)__shfl((int)v.zzz.l[i], src, 64);
     }
-    uint32_t cnt = s1 - s0 + 1;
-    if (cnt > serial_max) {
-        big_list[atomicAdd(big_count, 1u)] = b;
-        return;
-    }
-    G1Xyzz28 acc = xyzz28_canon(*partial_of(part, s0, 0, lo, seg_len));
-    for (uint32_t j = 1; j < cnt; j++) acc = add_inline(acc, xyzz28_canon(*partial_of(part, s0, j, lo, seg_len)));
-    buckets[b] = acc;
+    return o;
 }
 
-// Sum of `cnt` points fetched through `at(j)` by one block: strided partial sums, then an LDS
-// tree.  The result is valid in lane 0.  One inlined addition serves both stages.  LAZY_IN:
-// the fetched points come straight from k_accumulate and are canonicalised first.
+// The serial tails below are chains of dependent point additions (about 15 microseconds each for
+// a lone wave), so every sum is organised for small depth: a few strided terms per lane, then a
+// shuffle tree inside the wave, then a two-level tree across the block's four waves.  All stages
+// of one sum go through a single inlined addition (selected operands, one loop).
+static constexpr int kTreeBlock = 256;  // largest block of the tree kernels
+
+// Sum of `cnt` points fetched through `at(j)` by one block of 64, 128 or 256 lanes; valid in
+// lane 0.  LAZY_IN: the fetched points come straight from k_accumulate and are canonicalised
+// first.  Wide blocks give the smallest depth, narrow ones the least idle work in the tree levels.
 template <bool LAZY_IN, class At>
 __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at) {
-    const uint32_t t = threadIdx.x;
-    const uint32_t strided = (cnt + kSumBlock - 1) / kSumBlock;  // uniform over the block
+    const uint32_t t = threadIdx.x, lane = t & 63, width = blockDim.x;
+    const uint32_t waves = width >> 6;                         // 1, 2 or 4
+    const uint32_t wave_levels = waves == 4 ? 2 : (waves == 2 ? 1 : 0);
+    const uint32_t strided = (cnt + width - 1) / width;        // uniform over the block
     G1Xyzz28 acc = xyzz28_identity();
-    const uint32_t steps = strided + 7;  // 7 = log2(kSumBlock) tree levels
+    const uint32_t steps = strided + 6 + wave_levels;
     for (uint32_t step = 0; step < steps; step++) {
-        const G1Xyzz28 *src = nullptr;
+        G1Xyzz28 o = xyzz28_identity();
         if (step < strided) {
-            uint32_t j = step * kSumBlock + t;
-            if (j < cnt) src = at(j);
-        } else {
-            uint32_t stride = (kSumBlock / 2) >> (step - strided);
-            if (step == strided) {
-                sh[t] = acc;
-                __syncthreads();
+            uint32_t j = step * width + t;
+            if (j < cnt) {
+                o = *at(j);
+                if (LAZY_IN) o = xyzz28_canon(o);
             }
-            if (t < stride) src = &sh[t + stride];
+        } else if (step < strided + 6) {
+            const int off = 32 >> (step - strided);
+            o = shfl_down_point(acc, off, 64);
+            if ((int)lane >= off) o = xyzz28_identity();
+        } else {
+            if (step == strided + 6) {
+                if (lane == 0) sh[t >> 6] = acc;
+                __syncthreads();
+                acc = t < waves ? sh[t] : xyzz28_identity();
+            }
+            const int off = (int)(waves >> 1) >> (step - strided - 6);
+            o = shfl_down_point(acc, off, 4);
+            if (t >= waves || (int)t >= off) o = xyzz28_identity();
         }
-        if (src) {
-            G1Xyzz28 o = *src;
-            if (LAZY_IN && step < strided) o = xyzz28_canon(o);
-            acc = add_inline(acc, o);
-        }
-        if (step >= strided) {
-            __syncthreads();  // every read of this level is done
-            sh[t] = acc;
-            __syncthreads();
-        }
+        acc = add_inline(acc, o);
     }
+    __syncthreads();  // sh may be reused by the caller's next sum
     return acc;
 }
 
-// One block per queued bucket (grid-stride over the queue).
-__global__ __launch_bounds__(kSumBlock) void k_fixup_big(const uint32_t *__restrict__ start, uint32_t seg_len,
-                                                         const G1Xyzz28 *__restrict__ part,
-                                                         G1Xyzz28 *__restrict__ buckets,
-                                                         const uint32_t *__restrict__ big_count,
-                                                         const uint32_t *__restrict__ big_list) {
-    __shared__ G1Xyzz28 sh[kSumBlock];
-    const uint32_t count = *big_count;
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        uint32_t b = big_list[i];
-        uint32_t lo = start[b], hi = start[b + 1];
-        uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
-        G1Xyzz28 acc =
-            block_sum<true>(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
-        if (threadIdx.x == 0) buckets[b] = acc;
-        __syncthreads();
-    }
+// Buckets cut into more partials than a lane group handles go to the block path; the queue is
+// built before the accumulation (it depends only on the bucket bounds).
+__global__ __launch_bounds__(256) void k_classify(const uint32_t *__restrict__ start, uint32_t nbuckets,
+                                                 uint32_t seg_len, uint32_t group_cap,
+                                                 uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    uint32_t lo = start[b], hi = start[b + 1];
+    if (lo == hi) return;
+    uint32_t cnt = (hi - 1) / seg_len - lo / seg_len + 1;
+    if (cnt > group_cap) big_list[atomicAdd(big_count, 1u)] = b;
 }
 
-// ------------------------------------------------------------------------------------------
-// 6. reduction  sum_b (b + 1) B_b
-// ------------------------------------------------------------------------------------------
-// One lane per chunk of kChunk consecutive elements of A:
-//   R[t]  = sum_j A[t*kChunk + j]
-//   LW[t] = sum_j (j + off) A[t*kChunk + j]          (off = 1 on the bucket level, else 0)
-// by the running-sum recurrence run += A[b]; sum += run, highest b first.  Both updates go
-// through one inlined addition with selected operands.
-__global__ __launch_bounds__(kBlock) void k_reduce_level(const G1Xyzz28 *__restrict__ A, uint32_t n, int off,
-                                                         G1Xyzz28 *__restrict__ LW, G1Xyzz28 *__restrict__ R,
-                                                         uint32_t nchunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    uint32_t lo = t * kChunk;
-    uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-    G1Xyzz28 run = xyzz28_identity(), sum = xyzz28_identity();
-    const uint32_t steps = 2 * (hi - lo);
-    for (uint32_t step = 0; step < steps; step++) {
-        uint32_t b = hi - 1 - (step >> 1);
-        bool to_run = (step & 1) == 0;
-        if (!to_run && b == lo && !off) break;  // weight 0 for the chunk's first element
-        G1Xyzz28 x = to_run ? run : sum;
-        G1Xyzz28 y = to_run ? A[b] : run;
-        G1Xyzz28 r = add_inline(x, y);
-        if (to_run) {
-            run = r;
-        } else {
-            sum = r;
+// Blocks [0, group_blocks): a group of 2^g_log lanes per bucket; each lane adds up to per_lane of
+// the bucket's partials (stride 2^g_log), then a shuffle tree joins the group.  Whole buckets
+// (written by k_accumulate in its lazy form) and empty ones pass through the same code.
+// Blocks behind them: one block per queued bucket (grid-stride over the queue).
+__global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
+                                                      uint32_t seg_len, const G1Xyzz28 *__restrict__ part,
+                                                      G1Xyzz28 *__restrict__ buckets, uint32_t g_log,
+                                                      uint32_t per_lane, uint32_t group_blocks,
+                                                      const uint32_t *__restrict__ big_count,
+                                                      const uint32_t *__restrict__ big_list) {
+    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    if (blockIdx.x >= group_blocks) {
+        const uint32_t count = *big_count;
+        for (uint32_t i = blockIdx.x - group_blocks; i < count; i += gridDim.x - group_blocks) {
+            uint32_t b = big_list[i];
+            uint32_t lo = start[b], hi = start[b + 1];
+            uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
+            G1Xyzz28 acc =
+                block_sum<true>(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
+            if (threadIdx.x == 0) buckets[b] = acc;
+        }
+        return;
+    }
+    const uint32_t G = 1u << g_log;
+    const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = (uint32_t)(gl >> g_log), r = (uint32_t)gl & (G - 1);
+    const bool valid = b < nbuckets;
+    uint32_t lo = 0, hi = 0, s0 = 0, cnt = 0;
+    if (valid) {
+        lo = start[b];
+        hi = start[b + 1];
+        if (lo != hi) {
+            s0 = lo / seg_len;
+            cnt = (hi - 1) / seg_len - s0 + 1;
         }
     }
-    LW[t] = sum;
-    R[t] = run;
-}
-
-struct SumDesc {
-    uint32_t in_off[kMaxLevels];
-    uint32_t n[kMaxLevels];
-    uint32_t out_off[kMaxLevels];
-};
-
-static constexpr uint32_t kSumPerBlock = 4 * kSumBlock;
-
-// Plain sums: block (x, level) adds elements [x*kSumPerBlock, (x+1)*kSumPerBlock) of that
-// level's array.
-__global__ __launch_bounds__(kSumBlock) void k_sum_pass(const G1Xyzz28 *__restrict__ in, G1Xyzz28 *__restrict__ out,
-                                                        SumDesc d) {
-    __shared__ G1Xyzz28 sh[kSumBlock];
-    const int lev = blockIdx.y;
-    const uint32_t n = d.n[lev];
-    const uint32_t base = blockIdx.x * kSumPerBlock;
-    if (base >= n) return;  // uniform per block
-    const G1Xyzz28 *src = in + d.in_off[lev] + base;
-    uint32_t cnt = n - base < kSumPerBlock ? n - base : kSumPerBlock;
-    G1Xyzz28 acc = block_sum<false>(cnt, sh, [&](uint32_t j) { return src + j; });
-    if (threadIdx.x == 0) out[d.out_off[lev] + blockIdx.x] = acc;
-}
-
-// Horner over the level sums: total = s_0 + 4 (s_1 + 4 (s_2 + ...)); Jacobian result.
-__global__ void k_finish(const G1Xyzz28 *__restrict__ sums, SumDesc d, int nlev, G1Jac *__restrict__ out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    G1Xyzz28 acc = sums[d.in_off[nlev - 1]];
-    for (int l = nlev - 2; l >= 0; l--) {
-        for (int k = 0; k < kChunkLog; k++) acc = xyzz28_dbl(acc);
-        acc = add_inline(acc, sums[d.in_off[l]]);
+    const bool queued = cnt > per_lane * G;
+    G1Xyzz28 acc = xyzz28_identity();
+    // strided terms: as many rounds as the longest bucket of this wave needs
+    const uint32_t need = queued ? 0u : (cnt + G - 1) >> g_log;
+    uint32_t step = 0;
+    int off = (int)(G >> 1);
+    for (;;) {
+        G1Xyzz28 o = xyzz28_identity();
+        if (__any(step < need)) {  // the same answer in every lane of the wave
+            const uint32_t j = step * G + r;
+            if (!queued && j < cnt) {
+                // a bucket inside one segment was stored whole; otherwise partial j of its run
+                o = xyzz28_canon(cnt == 1 ? buckets[b] : *partial_of(part, s0, j, lo, seg_len));
+            }
+            step++;
+        } else {
+            if (off == 0) break;
+            o = shfl_down_point(acc, off, (int)G);
+            if ((int)r >= off) o = xyzz28_identity();
+            off >>= 1;
+        }
+        acc = add_inline(acc, o);
     }
-    *out = xyzz_to_jac(xyzz28_to(acc));
+    if (valid && r == 0 && !queued) buckets[b] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// 6. reduction  S = sum_b (b + 1) B_b  over nb = H * L buckets, b = hi * L + lo:
+//      S = sum_i 2^i T_i + T_all,
+//      T_i        = sum of the column sums C[lo] with bit i of lo set            (i < lbits)
+//      T_(lbits+i) = sum of the row sums R[hi] with bit i of hi set               (i < hbits)
+//      T_all      = sum of all buckets,
+//    with R[hi] = sum_lo B[hi*L + lo] and C[lo] = sum_hi B[hi*L + lo]: two additions per bucket,
+//    then sums over at most L or H elements, then one short Horner chain.
+// ------------------------------------------------------------------------------------------
+// blocks [0, H): row sums; blocks [H, H + L): column sums
+__global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(const G1Xyzz28 *__restrict__ B, uint32_t H, uint32_t L,
+                                                             G1Xyzz28 *__restrict__ R, G1Xyzz28 *__restrict__ C) {
+    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    const uint32_t i = blockIdx.x;
+    const bool row = i < H;
+    const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
+    const size_t stride = row ? 1 : L;
+    G1Xyzz28 acc = block_sum<false>(row ? L : H, sh, [&](uint32_t j) { return base + (size_t)j * stride; });
+    if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
+}
+
+// block i < lbits: T_i over C; lbits <= i < lbits + hbits: T_i over R; block lbits + hbits: T_all
+__global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restrict__ R, uint32_t hbits,
+                                                         const G1Xyzz28 *__restrict__ C, uint32_t lbits,
+                                                         G1Xyzz28 *__restrict__ T) {
+    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    const uint32_t i = blockIdx.x;
+    const bool all = i == lbits + hbits, low = all || i < lbits;
+    const G1Xyzz28 *A = low ? C : R;
+    const uint32_t nbits = low ? lbits : hbits;
+    const uint32_t bit = all ? 31u : (low ? i : i - lbits);
+    // j runs over the indices with `bit` removed; put a one back in at that position
+    G1Xyzz28 acc = block_sum<false>(all ? 1u << nbits : 1u << (nbits - 1), sh, [&](uint32_t j) {
+        return A + (all ? j : ((((j >> bit) << 1) | 1u) << bit | (j & ((1u << bit) - 1))));
+    });
+    if (threadIdx.x == 0) T[i] = acc;
+}
+
+// One wave.  Lane d forms the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2); lane 0 then runs
+// S = (..(U_top * 8 + U_(top-1)) * 8 + ..) + U_0 + T_all.  Jacobian result.
+__global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t nbits, G1Jac *__restrict__ out) {
+    const uint32_t d = threadIdx.x;
+    const uint32_t ndig = (nbits + 2) / 3;
+    auto term = [&](uint32_t bit) { return (d < ndig && bit < nbits) ? T[bit] : xyzz28_identity(); };
+    // program: (double | add operand) steps through one inlined doubling and one inlined addition
+    G1Xyzz28 acc = term(3 * d + 2);
+    G1Xyzz28 own = xyzz28_identity();
+    const uint32_t steps = 4 + 4 * (ndig - 1) + 1;
+    for (uint32_t step = 0; step < steps; step++) {
+        bool dbl;
+        G1Xyzz28 o = xyzz28_identity();
+        if (step < 4) {
+            dbl = (step & 1) == 0;
+            if (!dbl) o = term(3 * d + (step == 1 ? 1 : 0));
+        } else if (step < steps - 1) {
+            if (step == 4) {
+                own = acc;                       // U_d
+                acc = shfl_point(own, (int)ndig - 1);  // every lane follows lane 0's chain
+            }
+            const uint32_t q = step - 4;         // groups of (dbl, dbl, dbl, add U_dig)
+            dbl = (q & 3) != 3;
+            if (!dbl) o = shfl_point(own, (int)(ndig - 2 - (q >> 2)));
+        } else {
+            if (step == 4) {
+                own = acc;
+                acc = shfl_point(own, 0);
+            }
+            dbl = false;
+            o = T[nbits];  // T_all
+        }
+        if (dbl) {
+            G1Xyzz28 t = acc;
+            acc = dbl_cold(&t);
+        } else {
+            acc = add_inline(acc, o);
+        }
+    }
+    if (d == 0) *out = xyzz_to_jac(xyzz28_to(acc));
 }
 
 // out = sum of n Jacobian points (n is the number of GPUs: a handful)
@@ -460,10 +527,11 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     const uint32_t nb = pl.nbuckets;
     hipStream_t st = ctx->stream;
 
-    // segment length: balance accumulation depth against fix-up depth for small inputs, keep
-    // about 2^20 segments for large ones
+    // Segment length: for small inputs balance the accumulation depth (seg_len mixed additions in
+    // a row) against the fix-up depth; for large ones keep about 2^20 segments (several rounds of
+    // resident lanes, which evens out the tail of the kernel).
     const double per_bucket = (double)total / nb;
-    uint32_t seg_len = (uint32_t)std::max<double>(
+    const uint32_t seg_len = (uint32_t)std::max<double>(
         1.0, std::max(std::ceil(std::sqrt(per_bucket)), std::ceil((double)total / 1048576.0)));
     const size_t nseg = (total + seg_len - 1) / seg_len;
 
@@ -493,79 +561,45 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
     record(ctx, PH_BOUNDS);
     hipLaunchKernelGGL(k_bounds, dim3(cdiv(total, 256)), dim3(256), 0, st, keys_b, total, nb, start);
+    // Fix-up shape: a typical bucket is cut into about per_bucket / seg_len + 1 partials; a group
+    // of 2^g_log lanes takes up to per_lane partials per lane, anything longer (skewed digit
+    // distributions: the narrow top window, repeated scalars) goes to the block path.
+    const double typical = per_bucket / seg_len + 1.0;
+    // wider groups shorten the chain of dependent additions but leave lanes idle in the tree
+    // levels: widen only while the kernel stays below about two waves per SIMD
+    uint32_t g_log = 0;
+    while (g_log < 5 && (double)(2u << g_log) < typical && ((size_t)nb << (g_log + 1)) <= 131072) g_log++;
+    // heavy buckets sit next to each other (the narrow top window fills the lowest bucket numbers),
+    // so with many buckets a generous serial bound costs little and the block path is kept for the
+    // really long ones; with few buckets depth is all that matters
+    const uint32_t per_lane = std::max<uint32_t>(((size_t)nb << g_log) > 65536 ? 16u : 3u,
+                                                 (uint32_t)std::ceil(2.0 * typical / (1u << g_log)));
+    const uint32_t group_blocks = cdiv((size_t)nb << g_log, kTreeBlock);
+    const uint32_t big_blocks = std::min<uint32_t>(nb, 1024u);
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, per_lane << g_log,
+                       big_count, big_list);
     record(ctx, PH_ACCUM);
     hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
                        seg_len, table, buckets, part);
     record(ctx, PH_FIXUP);
-    PLONK_HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
-    // a typical bucket is cut into per_bucket / seg_len partials; only buckets well above
-    // that (skew) take the block-per-bucket path
-    const uint32_t serial_max = std::max<uint32_t>(16u, 2u * (uint32_t)std::ceil(per_bucket / seg_len) + 2u);
-    hipLaunchKernelGGL(k_fixup, dim3(cdiv(nb, kBlock)), dim3(kBlock), 0, st, start, nb, seg_len, part, buckets,
-                       serial_max, big_count, big_list);
-    hipLaunchKernelGGL(k_fixup_big, dim3(std::min<uint32_t>(nb, 1024u)), dim3(kSumBlock), 0, st, start, seg_len, part,
-                       buckets, big_count, big_list);
+    hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, st, start, nb, seg_len, part,
+                       buckets, g_log, per_lane, group_blocks, big_count, big_list);
     record(ctx, PH_REDUCE);
-
-    // ---- reduction levels
-    uint32_t level_n[kMaxLevels + 1];
-    int nlev = 0;
-    level_n[0] = nb;
-    size_t lw_total = 0;
-    while (true) {
-        uint32_t nchunks = (level_n[nlev] + kChunk - 1) / kChunk;
-        level_n[nlev + 1] = nchunks;
-        lw_total += nchunks;
-        nlev++;
-        if (nchunks <= 1) break;
-    }
-    if (nlev > kMaxLevels) return PLONK_HIP_ERR_INVALID_ARG;
-    PLONK_TRY(buf_reserve(ctx, ctx->red_a, (size_t)level_n[1] * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_b, (size_t)(nlev > 1 ? level_n[2] : 1) * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_lw, lw_total * sizeof(G1Xyzz28)));
-    G1Xyzz28 *lw = (G1Xyzz28 *)ctx->red_lw.ptr;
-    SumDesc desc = {};
     {
-        const G1Xyzz28 *A = buckets;
-        uint32_t off = 0;
-        for (int l = 0; l < nlev; l++) {
-            G1Xyzz28 *Rbuf = (G1Xyzz28 *)((l & 1) ? ctx->red_b.ptr : ctx->red_a.ptr);
-            uint32_t nchunks = level_n[l + 1];
-            hipLaunchKernelGGL(k_reduce_level, dim3(cdiv(nchunks, kBlock)), dim3(kBlock), 0, st, A, level_n[l],
-                               l == 0 ? 1 : 0, lw + off, Rbuf, nchunks);
-            desc.in_off[l] = off;
-            desc.n[l] = nchunks;
-            off += nchunks;
-            A = Rbuf;
-        }
+        const uint32_t nbits = (uint32_t)pl.c - 1;
+        const uint32_t lbits = (nbits + 1) / 2, hbits = nbits - lbits;
+        const uint32_t L = 1u << lbits, H = 1u << hbits;
+        PLONK_TRY(buf_reserve(ctx, ctx->red_a, ((size_t)H + L + nbits + 1) * sizeof(G1Xyzz28)));
+        G1Xyzz28 *R = (G1Xyzz28 *)ctx->red_a.ptr, *C = R + H, *T = C + L;
+        // one sum per block: wide blocks (small depth) while they are few, one wave per sum once
+        // there is a sum for every SIMD (the tree levels of a wide block are mostly idle lanes)
+        const uint32_t sums = H + L;
+        const uint32_t width = sums >= 1024 ? 64u : (sums >= 512 ? 128u : 256u);
+        hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, buckets, H, L, R, C);
+        hipLaunchKernelGGL(k_bit_sums, dim3(nbits + 1), dim3(kTreeBlock), 0, st, R, hbits, C, lbits, T);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, T, nbits, d_out);
     }
-    // ---- plain sums of every level's LW array
-    size_t max_blocks_total = 0;
-    for (int l = 0; l < nlev; l++) max_blocks_total += cdiv(desc.n[l], kSumPerBlock);
-    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_a, max_blocks_total * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, ctx->red_sum_b, max_blocks_total * sizeof(G1Xyzz28)));
-    const G1Xyzz28 *in = lw;
-    G1Xyzz28 *outs[2] = {(G1Xyzz28 *)ctx->red_sum_a.ptr, (G1Xyzz28 *)ctx->red_sum_b.ptr};
-    int flip = 0;
-    while (true) {
-        uint32_t max_n = 0, max_blocks = 0, off = 0;
-        for (int l = 0; l < nlev; l++) {
-            uint32_t blocks = cdiv(desc.n[l], kSumPerBlock);
-            desc.out_off[l] = off;
-            off += blocks;
-            max_n = std::max(max_n, desc.n[l]);
-            max_blocks = std::max(max_blocks, blocks);
-        }
-        if (max_n <= 1) break;
-        hipLaunchKernelGGL(k_sum_pass, dim3(max_blocks, nlev), dim3(kSumBlock), 0, st, in, outs[flip], desc);
-        for (int l = 0; l < nlev; l++) {
-            desc.in_off[l] = desc.out_off[l];
-            desc.n[l] = cdiv(desc.n[l], kSumPerBlock);
-        }
-        in = outs[flip];
-        flip ^= 1;
-    }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, st, in, desc, nlev, d_out);
     record(ctx, PH_COUNT);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
