@@ -142,6 +142,10 @@ int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, do
  * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
 int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
 /* Window plan in force: bits per window, windows, buckets. */
+/* Measured lane-operations/s of one VALU instruction (op: 0 v_lshrrev_b64, 1 v_lshl_add_u64,
+ * 2 v_alignbit_b32, 3 v_and_b32, 4 v_add3_u32, 5 v_mad_i64_i32, 6 v_ashrrev_i64, 7 v_mul_lo_u32,
+ * 8 v_mad_u64_u32, 9 v_sub_u32): the per-instruction costs behind the kernels' instruction budgets. */
+int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
 /* Measured bytes/s of a random gather of whole 128-byte lines from a table of table_bytes: the
  * memory-side ceiling of the bucket accumulation's table reads. */
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);

@@ -114,6 +114,11 @@ class Backend:
         self._check(self._lib.plonk_hip_msm_phase_ms(self._ctx, ms))
         return {self._lib.plonk_hip_msm_phase_name(i).decode(): float(ms[i]) for i in range(6)}
 
+    def bench_op_rate(self, op):
+        v = ctypes.c_double()
+        self._check(self._lib.plonk_hip_bench_op_rate(self._ctx, op, ctypes.byref(v)))
+        return v.value
+
     def bench_gather_rate(self, table_bytes):
         v = ctypes.c_double()
         self._check(self._lib.plonk_hip_bench_gather_rate(self._ctx, table_bytes, ctypes.byref(v)))

@@ -295,6 +295,12 @@ int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, do
     return bench_mad_mix(ctx, extra, blocks_per_cu, mads_per_second, clock_ghz);
 }
 
+int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) {
+    PLONK_ENTER(ctx);
+    if (!ops_per_second) return PLONK_HIP_ERR_INVALID_ARG;
+    return bench_op_rate(ctx, op, ops_per_second);
+}
+
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
     PLONK_ENTER(ctx);
     if (!bytes_per_second) return PLONK_HIP_ERR_INVALID_ARG;

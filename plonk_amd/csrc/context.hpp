@@ -99,6 +99,7 @@ int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, 
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
 int bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second, double *clock_ghz);
 int bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
+int bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
 int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 
 // srs.hip

@@ -252,4 +252,69 @@ int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_
     return PLONK_HIP_OK;
 }
 
+// Issue rate of single VALU instructions: 8 independent registers (pairs) per lane, 32 instructions
+// per loop iteration.  OP selects the instruction (see bench_op_rate).
+template <int OP>
+__global__ __launch_bounds__(256) void k_op_rate(uint32_t *__restrict__ out, uint32_t seed, int iters) {
+    uint32_t a = seed ^ (threadIdx.x * 2654435761u), b = (seed + blockIdx.x * 40503u + 12345u) | 1u;
+    uint64_t r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = ((uint64_t)(a + j) << 17) | b;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (OP == 0) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(r[j]));
+                if (OP == 1) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r[j]) : "v"(r[(j + 1) & 7]));
+                if (OP == 2) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(*(uint32_t *)&r[j]) : "v"(a));
+                if (OP == 3) asm volatile("v_and_b32 %0, %1, %0" : "+v"(*(uint32_t *)&r[j]) : "v"(b));
+                if (OP == 4) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*(uint32_t *)&r[j]) : "v"(a), "v"(b));
+                if (OP == 5) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(r[j]) : "v"(a), "v"(b) : "vcc");
+                if (OP == 6) asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(r[j]));
+                if (OP == 7) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(*(uint32_t *)&r[j]) : "v"(b));
+                if (OP == 8) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[j]) : "v"(a), "v"(b) : "vcc");
+                if (OP == 9) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(*(uint32_t *)&r[j]) : "v"(a));
+            }
+        }
+    }
+    uint64_t sacc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sacc ^= r[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)sacc ^ (uint32_t)(sacc >> 32);
+}
+
+// Wave-instructions per second per SIMD-equivalent are derived by the caller; this returns lane
+// operations per second for instruction `op`:
+// 0 v_lshrrev_b64, 1 v_lshl_add_u64, 2 v_alignbit_b32, 3 v_and_b32, 4 v_add3_u32, 5 v_mad_i64_i32,
+// 6 v_ashrrev_i64, 7 v_mul_lo_u32, 8 v_mad_u64_u32, 9 v_sub_u32.
+int bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) {
+    const int blocks = 256 * 8, threads = 256, iters = 2048;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4));
+    uint32_t *out = (uint32_t *)ctx->scratch_c.ptr;
+    hipEvent_t e0, e1;
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e0));
+    PLONK_HIP_TRY(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        PLONK_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+#define PLONK_OP_CASE(N) case N: hipLaunchKernelGGL(k_op_rate<N>, dim3(blocks), dim3(threads), 0, ctx->stream, out, 11u + rep, iters); break;
+        switch (op) {
+            PLONK_OP_CASE(0) PLONK_OP_CASE(1) PLONK_OP_CASE(2) PLONK_OP_CASE(3) PLONK_OP_CASE(4)
+            PLONK_OP_CASE(5) PLONK_OP_CASE(6) PLONK_OP_CASE(7) PLONK_OP_CASE(8) PLONK_OP_CASE(9)
+            default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PLONK_HIP_ERR_INVALID_ARG;
+        }
+#undef PLONK_OP_CASE
+        PLONK_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        PLONK_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ops_per_second = (double)blocks * threads * (double)iters * 32.0 / (best * 1e-3);
+    return PLONK_HIP_OK;
+}
+
 }  // namespace plonk

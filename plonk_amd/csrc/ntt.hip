@@ -272,8 +272,8 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
 // cross HBM as 8 x 32-bit limbs (values below 2^256; canonical when `canonical_out` is set, as
 // on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is 1; with
 // do_scale 2 (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
-template <bool DIF>
-__global__ __launch_bounds__(256) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
+template <bool DIF, int GMAX>
+__global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
                                                   uint32_t tpb_log, const Tw29 *__restrict__ tw, size_t batch_stride,
                                                   Fr29 scale, Fr29 scale_upper, int do_scale, int canonical_out) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -285,47 +285,57 @@ __global__ __launch_bounds__(256) void k_ntt_pass(Fr *__restrict__ data, uint32_
     const size_t first_tile = (size_t)blockIdx.x << tpb_log;
     const size_t s0_mask = ((size_t)1 << s0) - 1;
 
+    // Neighbouring lanes take neighbouring addresses: in the pass with s0 = 0 a tile is contiguous
+    // (j runs fastest); in a strided pass the tiles of a block are adjacent columns (the tile
+    // index runs fastest), so that each row of the block is one contiguous piece of memory.
+    const bool tile_fastest = s0 != 0;
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
-        const uint32_t tb = q >> k, j = q & (tile_n - 1);
+        const uint32_t tb = tile_fastest ? q & ((1u << tpb_log) - 1) : q >> k;
+        const uint32_t j = tile_fastest ? q >> tpb_log : q & (tile_n - 1);
         const size_t T = first_tile + tb;
         const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
         lds_put(lds + tb * tile_words, j, fr29_pack(vec[idx]));
     }
     __syncthreads();
 
-    const uint32_t items_per_tile = tile_n >> 3, items = items_per_tile << tpb_log;
-    const uint32_t nrounds = (k + 2) / 3;
+    // a work item is 2^GMAX elements: GMAX = 3 keeps more stages in registers per LDS round trip,
+    // GMAX = 2 halves the register footprint (four waves per SIMD instead of two)
+    constexpr uint32_t NE = 1u << GMAX;
+    const uint32_t items_per_tile = tile_n >> GMAX, items = items_per_tile << tpb_log;
+    const uint32_t nrounds = (k + GMAX - 1) / GMAX;
     for (uint32_t r = 0; r < nrounds; r++) {
         // DIT walks the in-tile bits upwards, DIF downwards; the last round takes what is left
         uint32_t g, b0;
         if (DIF) {
-            uint32_t top = k - 3 * r;
-            g = top < 3 ? top : 3;
+            uint32_t top = k - GMAX * r;
+            g = top < (uint32_t)GMAX ? top : (uint32_t)GMAX;
             b0 = top - g;
         } else {
-            b0 = 3 * r;
-            g = k - b0 < 3 ? k - b0 : 3;
+            b0 = GMAX * r;
+            g = k - b0 < (uint32_t)GMAX ? k - b0 : (uint32_t)GMAX;
         }
         for (uint32_t w = threadIdx.x; w < items; w += blockDim.x) {
             const uint32_t tb = w / items_per_tile, item = w % items_per_tile;
             const size_t t_lo = (first_tile + tb) & s0_mask;
             uint32_t *tile = lds + tb * tile_words;
-            if (g == 3) {
+            if (GMAX == 3 && g == 3) {
                 ntt_round<DIF, 3, 8>(tile, item, b0, s0, log_n, t_lo, tw);
             } else if (g == 2) {
-                // two groups of four, one after the other (keeps the register footprint of this
-                // rarely taken branch below that of the three-stage round)
+                // groups of four, one after the other (for GMAX = 3 this keeps the register
+                // footprint of the rarely taken branch below that of the three-stage round)
 #pragma unroll 1
-                for (uint32_t h = 0; h < 2; h++) ntt_round<DIF, 2, 4>(tile, 2 * item + h, b0, s0, log_n, t_lo, tw);
+                for (uint32_t h = 0; h < NE / 4; h++)
+                    ntt_round<DIF, 2, 4>(tile, (NE / 4) * item + h, b0, s0, log_n, t_lo, tw);
             } else {
-                ntt_round<DIF, 1, 8>(tile, item, b0, s0, log_n, t_lo, tw);
+                ntt_round<DIF, 1, (int)NE>(tile, item, b0, s0, log_n, t_lo, tw);
             }
         }
         __syncthreads();
     }
 
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
-        const uint32_t tb = q >> k, j = q & (tile_n - 1);
+        const uint32_t tb = tile_fastest ? q & ((1u << tpb_log) - 1) : q >> k;
+        const uint32_t j = tile_fastest ? q >> tpb_log : q & (tile_n - 1);
         const size_t T = first_tile + tb;
         const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
         Fr29 v = lds_get(lds + tb * tile_words, j);
@@ -389,22 +399,46 @@ __global__ __launch_bounds__(256) void k_mul_halves(Fr *__restrict__ data, size_
     *q = fe_mul(*q, p < n / 2 ? lo_half : hi_half);
 }
 
+// stages kept in registers per LDS round trip (experiment switch: PLONK_NTT_G=2|3)
+static int ntt_gmax() {
+    static int g = [] {
+        const char *e = getenv("PLONK_NTT_G");
+        return (e && e[0] == '2') ? 2 : 3;
+    }();
+    return g;
+}
+
 static constexpr int kMaxTileLog = 11;  // 2048 elements = 74 KiB of LDS
 
 struct PassPlan {
     int npass;
-    uint32_t s0[4], s1[4];
+    uint32_t s0[6], s1[6];
 };
-// log_n >= 3: ceil(log_n / 11) passes of nearly equal width (each at least 3 stages)
+// log_n >= 3.  The pass over the low stages works on contiguous tiles and takes up to 11 stages.
+// The stages above it are strided: their blocks hold several adjacent columns so that memory is
+// still touched in contiguous rows, which limits a strided pass to 9 stages (4 columns of 512) --
+// or 10 (2 columns) when that saves a whole pass.
 static PassPlan make_plan(uint32_t log_n) {
     PassPlan p;
-    p.npass = (int)((log_n + kMaxTileLog - 1) / kMaxTileLog);
-    uint32_t base = log_n / p.npass, extra = log_n % p.npass, s = 0;
-    for (int i = 0; i < p.npass; i++) {
-        uint32_t k = base + ((uint32_t)i < extra ? 1 : 0);
-        p.s0[i] = s;
-        p.s1[i] = s + k;
-        s += k;
+    uint32_t low = log_n < (uint32_t)kMaxTileLog ? log_n : (uint32_t)kMaxTileLog;
+    uint32_t rest = log_n - low;
+    if (rest > 0 && rest < 3) {  // every pass needs at least 3 stages
+        low -= 3 - rest;
+        rest = 3;
+    }
+    p.npass = 1;
+    p.s0[0] = 0;
+    p.s1[0] = low;
+    if (rest > 0) {
+        uint32_t np = rest <= 11 ? 1 : (rest + 8) / 9;
+        uint32_t base = rest / np, extra = rest % np, s = low;
+        for (uint32_t i = 0; i < np; i++) {
+            uint32_t k = base + (i < extra ? 1 : 0);
+            p.s0[p.npass] = s;
+            p.s1[p.npass] = s + k;
+            s += k;
+            p.npass++;
+        }
     }
     return p;
 }
@@ -442,9 +476,13 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS
-        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true>,
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true, 3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false>,
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false, 3>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true, 2>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false, 2>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         lds_opt_in = true;
     }
@@ -453,19 +491,27 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         uint32_t k = pl.s1[i] - pl.s0[i];
         bool last = q == pl.npass - 1;
         // small tiles: several per block so that a block has 1024 elements (128 work items)
-        uint32_t tpb_log = k < 10 ? 10 - k : 0;
+        // tiles per block: up to 1024 elements per block in the contiguous pass (small tiles),
+        // up to 2048 in a strided pass (adjacent columns: 128-byte rows from 4 columns on)
+        const uint32_t block_log = pl.s0[i] == 0 ? 10 : 11;
+        uint32_t tpb_log = k < block_log ? block_log - k : 0;
+        if (pl.s0[i] != 0 && tpb_log > pl.s0[i]) tpb_log = pl.s0[i];
         if ((n >> k) < ((size_t)1 << tpb_log)) tpb_log = (uint32_t)(log_n - k);
         const uint32_t tile_n = 1u << k;
         const size_t lds = (size_t)(9 * tile_n + (tile_n >> 5) + 1) * 4 << tpb_log;
-        const unsigned threads = k >= 11 ? 256 : 128;
+        const int gmax = ntt_gmax();
+        const unsigned threads = gmax == 2 ? 256 : (k + tpb_log >= 11 ? 256 : 128);
         dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
+        const int sm = (last && scale) ? scale_mode : 0, canon = last ? 1 : 0;
+#define PLONK_LAUNCH_PASS(DIFV, G)                                                                              \
+    hipLaunchKernelGGL((k_ntt_pass<DIFV, G>), grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i], \
+                       tpb_log, tw, n, sc, sc_up, sm, canon)
         if (dif) {
-            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
-                               tpb_log, tw, n, sc, sc_up, (last && scale) ? scale_mode : 0, last ? 1 : 0);
+            if (gmax == 2) PLONK_LAUNCH_PASS(true, 2); else PLONK_LAUNCH_PASS(true, 3);
         } else {
-            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i],
-                               tpb_log, tw, n, sc, sc_up, (last && scale) ? scale_mode : 0, last ? 1 : 0);
+            if (gmax == 2) PLONK_LAUNCH_PASS(false, 2); else PLONK_LAUNCH_PASS(false, 3);
         }
+#undef PLONK_LAUNCH_PASS
     }
     return PLONK_HIP_OK;
 }

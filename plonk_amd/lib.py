@@ -63,6 +63,7 @@ SIGNATURES = {
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint32, ctypes.c_size_t, c_u64p, c_intp]),
     "plonk_hip_fr_quotient_coset_dev": (
         ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, c_intp]),
+    "plonk_hip_bench_op_rate": (ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_gather_rate": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_fr_eval_many": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
