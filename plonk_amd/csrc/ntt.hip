@@ -273,28 +273,38 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
 // on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is 1; with
 // do_scale 2 (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
 template <bool DIF, int GMAX>
-__global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(Fr *__restrict__ data, uint32_t log_n, uint32_t s0, uint32_t s1,
+__global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *src, Fr *dst, uint32_t log_n, uint32_t s0, uint32_t s1,
                                                   uint32_t tpb_log, const Tw29 *__restrict__ tw, size_t batch_stride,
-                                                  Fr29 scale, Fr29 scale_upper, int do_scale, int canonical_out) {
+                                                  Fr29 scale, Fr29 scale_upper, int do_scale, int canonical_out,
+                                                  int in_map, int out_map) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t k = s1 - s0;
     const uint32_t tile_n = 1u << k;
     const uint32_t tile_words = 9u * tile_n + (tile_n >> 5) + 1;
     const uint32_t block_elems = tile_n << tpb_log;
-    Fr *vec = data + (size_t)blockIdx.y * batch_stride;
+    const Fr *vec_in = src + (size_t)blockIdx.y * batch_stride;
+    Fr *vec = dst + (size_t)blockIdx.y * batch_stride;
     const size_t first_tile = (size_t)blockIdx.x << tpb_log;
     const size_t s0_mask = ((size_t)1 << s0) - 1;
 
     // Neighbouring lanes take neighbouring addresses: in the pass with s0 = 0 a tile is contiguous
     // (j runs fastest); in a strided pass the tiles of a block are adjacent columns (the tile
     // index runs fastest), so that each row of the block is one contiguous piece of memory.
-    const bool tile_fastest = s0 != 0;
+    // Address maps (in_map for the load, out_map for the store) fold the bit-reversal permutation
+    // of a natural-order transform into its two passes:
+    //   0  plain: element j of tile T
+    //   1  the tile's rows in bit-reversed order (strided pass)
+    //   2  pass with s0 = 0 only: element j of tile T lives at (rev(j) << (log_n - k)) | T
+    auto address = [&](int map, size_t T, uint32_t j) -> size_t {
+        const uint32_t jr = map ? (__brev(j) >> (32 - k)) : j;
+        if (map == 2) return ((size_t)jr << (log_n - k)) | T;
+        return ((T >> s0) << s1) | ((size_t)jr << s0) | (T & s0_mask);
+    };
+    const bool tile_fastest_in = s0 != 0 || in_map == 2, tile_fastest_out = s0 != 0 || out_map == 2;
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
-        const uint32_t tb = tile_fastest ? q & ((1u << tpb_log) - 1) : q >> k;
-        const uint32_t j = tile_fastest ? q >> tpb_log : q & (tile_n - 1);
-        const size_t T = first_tile + tb;
-        const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
-        lds_put(lds + tb * tile_words, j, fr29_pack(vec[idx]));
+        const uint32_t tb = tile_fastest_in ? q & ((1u << tpb_log) - 1) : q >> k;
+        const uint32_t j = tile_fastest_in ? q >> tpb_log : q & (tile_n - 1);
+        lds_put(lds + tb * tile_words, j, fr29_pack(vec_in[address(in_map, first_tile + tb, j)]));
     }
     __syncthreads();
 
@@ -334,10 +344,9 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(Fr *__restr
     }
 
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
-        const uint32_t tb = tile_fastest ? q & ((1u << tpb_log) - 1) : q >> k;
-        const uint32_t j = tile_fastest ? q >> tpb_log : q & (tile_n - 1);
-        const size_t T = first_tile + tb;
-        const size_t idx = ((T >> s0) << s1) | ((size_t)j << s0) | (T & s0_mask);
+        const uint32_t tb = tile_fastest_out ? q & ((1u << tpb_log) - 1) : q >> k;
+        const uint32_t j = tile_fastest_out ? q >> tpb_log : q & (tile_n - 1);
+        const size_t idx = address(out_map, first_tile + tb, j);
         Fr29 v = lds_get(lds + tb * tile_words, j);
         if (do_scale == 2) {
             v = fr29_mul_lazy(v, (idx >> (log_n - 1)) ? scale_upper : scale);
@@ -446,8 +455,12 @@ static PassPlan make_plan(uint32_t log_n) {
 // DIF (natural -> bit-reversed) or DIT (bit-reversed -> natural) butterflies over `batch`
 // vectors of 2^log_n elements; `scale` (if given, radix-2^256 Montgomery form) multiplies
 // every output element in the last pass.  Outputs are canonical.
+// With `natural` set (3 <= log_n <= kMaxNaturalLog) the permutation is folded into the passes:
+// DIF then takes natural order to natural order, DIT likewise; transforms of more than one pass
+// go through the context's transform workspace (the scattering pass cannot work in place).
+static constexpr uint32_t kMaxNaturalLog = 20;
 static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, bool inverse_tw, bool dif,
-                      const Fr *scale, const Fr *scale_upper = nullptr) {
+                      const Fr *scale, const Fr *scale_upper = nullptr, bool natural = false) {
     const size_t n = (size_t)1 << log_n;
     if (log_n <= 2) {
         // 2 or 4 points: natural-order transform plus the permutation the caller expects;
@@ -468,6 +481,21 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     const Tw29 *tw;
     PLONK_TRY(get_twiddles(ctx, log_n, inverse_tw, &tw));
     PassPlan pl = make_plan(log_n);
+    Fr *ws = nullptr;
+    if (natural) {
+        if (log_n < 3 || log_n > kMaxNaturalLog || scale_upper) return PLONK_HIP_ERR_INVALID_ARG;
+        if (log_n > (uint32_t)kMaxTileLog) {
+            // two passes of at most 10 stages: both sides keep rows of at least 64 bytes
+            const uint32_t low = log_n / 2;
+            pl.npass = 2;
+            pl.s0[0] = 0;
+            pl.s1[0] = low;
+            pl.s0[1] = low;
+            pl.s1[1] = log_n;
+            PLONK_TRY(buf_reserve(ctx, ctx->ntt_ws, batch * n * sizeof(Fr)));
+            ws = (Fr *)ctx->ntt_ws.ptr;
+        }
+    }
     // the split scale needs the s0 = 0 pass to come last, as it does for DIF
     if (scale_upper && (!dif || !scale)) return PLONK_HIP_ERR_INVALID_ARG;
     Fr29 sc = scale ? fr29_twiddle_from(*scale) : Fr29{};
@@ -493,7 +521,7 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         // small tiles: several per block so that a block has 1024 elements (128 work items)
         // tiles per block: up to 1024 elements per block in the contiguous pass (small tiles),
         // up to 2048 in a strided pass (adjacent columns: 128-byte rows from 4 columns on)
-        const uint32_t block_log = pl.s0[i] == 0 ? 10 : 11;
+        const uint32_t block_log = (pl.s0[i] == 0 && !(natural && pl.npass == 2)) ? 10 : 11;
         uint32_t tpb_log = k < block_log ? block_log - k : 0;
         if (pl.s0[i] != 0 && tpb_log > pl.s0[i]) tpb_log = pl.s0[i];
         if ((n >> k) < ((size_t)1 << tpb_log)) tpb_log = (uint32_t)(log_n - k);
@@ -503,9 +531,21 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         const unsigned threads = gmax == 2 ? 256 : (k + tpb_log >= 11 ? 256 : 128);
         dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
         const int sm = (last && scale) ? scale_mode : 0, canon = last ? 1 : 0;
-#define PLONK_LAUNCH_PASS(DIFV, G)                                                                              \
-    hipLaunchKernelGGL((k_ntt_pass<DIFV, G>), grid, dim3(threads), lds, ctx->stream, d, log_n, pl.s0[i], pl.s1[i], \
-                       tpb_log, tw, n, sc, sc_up, sm, canon)
+        // natural order: DIF = strided pass (rows stored reversed) then the s0 = 0 pass (scattered
+        // store); DIT is the mirror image with the maps on the loads
+        int in_map = 0, out_map = 0;
+        const Fr *src = d;
+        Fr *dst = d;
+        if (natural) {
+            const int map = pl.s0[i] == 0 ? 2 : 1;
+            if (dif) out_map = map; else in_map = map;
+            if (pl.npass == 2) {
+                if (q == 0) dst = ws; else src = ws;
+            }
+        }
+#define PLONK_LAUNCH_PASS(DIFV, G)                                                                               \
+    hipLaunchKernelGGL((k_ntt_pass<DIFV, G>), grid, dim3(threads), lds, ctx->stream, src, dst, log_n, pl.s0[i],    \
+                       pl.s1[i], tpb_log, tw, n, sc, sc_up, sm, canon, in_map, out_map)
         if (dif) {
             if (gmax == 2) PLONK_LAUNCH_PASS(true, 2); else PLONK_LAUNCH_PASS(true, 3);
         } else {
@@ -540,7 +580,13 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
     Fr ninv = fe_inv(fr_from_u64(n));
     if (coset_shift && inverse && fe_is_zero(*coset_shift)) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
     if (!inverse && coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
-    if (!inverse) {
+    if (log_n >= 3 && log_n <= kMaxNaturalLog) {
+        if (!inverse) {
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, true));
+        } else {
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, true));
+        }
+    } else if (!inverse) {
         PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr));
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);

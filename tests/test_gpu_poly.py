@@ -12,7 +12,7 @@ from tests.gpu_util import backend, rand_fr  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 9, 10, 11, 13])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 16])
 def test_ntt_matches_oracle(backend, log_n):
     rnd = random.Random(50 + log_n)
     n = 1 << log_n
@@ -41,6 +41,18 @@ def test_coset_ntt(backend):
     assert c.fr_from_mont(ev) == [o.poly_eval(co, shift * pow(w, j, o.R) % o.R) for j in range(n)]
     back = backend.fr_ntt(ev, inverse=True, shift=c.fr_to_mont([shift])[0])
     assert c.fr_from_mont(back) == co
+
+
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_ntt_beyond_the_two_pass_natural_order_path(backend, log_n):
+    # above 2^20 the butterflies run on the plain layout and a separate permutation follows
+    rnd = random.Random(70 + log_n)
+    n = 1 << log_n
+    data = np.frombuffer(rnd.randbytes(n * 32), dtype=np.uint64).reshape(1, n, 4).copy()
+    data[:, :, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    ev = backend.fr_ntt(data)
+    assert np.array_equal(ev[0], c.fr_ntt(data[0]))
+    assert np.array_equal(backend.fr_ntt(ev, inverse=True), data)
 
 
 def test_ntt_2_20_round_trip_and_oracle(backend):
