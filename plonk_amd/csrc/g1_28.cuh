@@ -45,7 +45,7 @@ PLONK_HD G1Xyzz28 xyzz28_dbl_affine(const Fq28 &x, const Fq28 &y) {
 
 // Keeps the instruction scheduler from interleaving two steps of the addition: every step is a
 // 392-multiply-add field product, so nothing is gained by overlapping them, while overlapping
-// lengthens live ranges past the 168 registers that three waves per SIMD allow.
+// lengthens live ranges and with them the register count.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PLONK_STEP() __builtin_amdgcn_sched_barrier(0)
 #else

@@ -139,7 +139,10 @@ __device__ __forceinline__ G1Affine28 read_line(const uint4 *buf, uint32_t lane)
     return pt;
 }
 
-__global__ __launch_bounds__(kBlock, 3) void k_accumulate(const uint32_t *__restrict__ keys,
+// Two waves per SIMD: the whole addition then lives in registers.  A third wave (168 registers)
+// spills about 60 bytes per lane and iteration, which showed up as 13 GB of write traffic per
+// 2^24-point launch and cost more than the extra wave hid.
+__global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                        uint32_t seg_len, const G1Affine28 *__restrict__ table,
