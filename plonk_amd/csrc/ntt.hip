@@ -206,8 +206,11 @@ __device__ __forceinline__ void lds_put(uint32_t *tile, uint32_t j, const Fr29 &
 // One round: G butterfly stages on the in-tile bits [b0, b0 + G).  A call handles NE elements:
 // NE / 2^G groups of 2^G elements whose tile indices differ exactly in those bits; `item` is the
 // work item's index inside the tile (tile_n / 8 of them).
-// Bounds (units of 2^255, capacity 64): DIT lets values grow by at most 1.81 per stage (19.4 after
-// the 10 stages of a pass, reduced when the pass stores); DIF reduces each sum back below 1.24.
+// Bounds (units of 2^255, capacity 64; r = 0.906): DIT lets values grow by at most 1.81 per stage
+// (19.4 after the 10 stages of a pass, reduced when the pass stores).  DIF lets the sums of a round
+// double per stage and reduces them once at the end of the round: with every element below
+// B = 4.1 at the start, sums reach 8 B = 32.6, one reduction step brings them below
+// 1 + 0.0943 * 32 < B again, a subtrahend is at most 4 B < 19 r, and products stay below 1.4.
 template <bool DIF, int G, int NE>
 __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_t b0, uint32_t s0, uint32_t log_n,
                                           size_t t_lo, const Tw29 *__restrict__ tw) {
@@ -252,8 +255,8 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
                 const uint32_t lo = u * GROUP + c, hi = lo | (1u << bb);
                 const Fr29 &w = twr[u * TW_PER_GROUP + ((1u << bb) - 1) + (c & ((1u << bb) - 1))];
                 if (DIF) {
-                    Fr29 sum = fr29_reduce_step(fr29_add_lazy(x[lo], x[hi]));
-                    x[hi] = fr29_mul_lazy(fr29_sub_lazy<2>(x[lo], x[hi]), w);
+                    Fr29 sum = fr29_add_lazy(x[lo], x[hi]);
+                    x[hi] = fr29_mul_lazy(fr29_sub_lazy<19>(x[lo], x[hi]), w);
                     x[lo] = sum;
                 } else {
                     Fr29 t = fr29_mul_lazy(x[hi], w);
@@ -262,6 +265,11 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
                 }
             }
         }
+    }
+    if (DIF) {
+        // the elements that were sums in the last stage (group bit 0 clear)
+#pragma unroll
+        for (uint32_t e = 0; e < (uint32_t)NE; e += 2) x[e] = fr29_reduce_step(x[e]);
     }
 #pragma unroll
     for (uint32_t e = 0; e < (uint32_t)NE; e++) lds_put(tile, jj[e], x[e]);

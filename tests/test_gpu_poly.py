@@ -31,6 +31,26 @@ def test_ntt_matches_oracle(backend, log_n):
             Om, c.fr_from_mont(ev[0]))
 
 
+@pytest.mark.parametrize("log_n", [3, 10, 11, 13, 20])
+def test_ntt_worst_case_growth_of_the_lazy_sums(backend, log_n):
+    # a constant vector of r - 1 makes every butterfly sum as large as it can get
+    n = 1 << log_n
+    co = c.fr_to_mont([o.R - 1]).reshape(1, 4).repeat(n, axis=0).reshape(1, n, 4).copy()
+    ev = backend.fr_ntt(co)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    want[0] = c.fr_to_mont([(n * (o.R - 1)) % o.R])[0]
+    assert np.array_equal(ev[0], want)
+    assert np.array_equal(backend.fr_ntt(ev, inverse=True), co)
+    assert np.array_equal(backend.fr_ntt(co, inverse=True)[0, 0], c.fr_to_mont([o.R - 1])[0])
+    # alternating r - 1, 0: the largest differences
+    alt = co.copy()
+    alt[0, 1::2] = 0
+    ev = backend.fr_ntt(alt)
+    if log_n <= 13:
+        assert np.array_equal(ev[0], c.fr_ntt(alt[0]))
+    assert np.array_equal(backend.fr_ntt(ev, inverse=True), alt)
+
+
 def test_coset_ntt(backend):
     rnd = random.Random(60)
     n = 256
