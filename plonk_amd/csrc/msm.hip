@@ -532,10 +532,12 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
 
     // Segment length: for small inputs balance the accumulation depth (seg_len mixed additions in
     // a row) against the fix-up depth; for large ones keep about 2^20 segments (several rounds of
-    // resident lanes, which evens out the tail of the kernel).
+    // resident lanes, which evens out the tail of the kernel); in between, at least 2^18 segments
+    // of up to 32 positions (fewer partial sums for the fix-up).
     const double per_bucket = (double)total / nb;
-    const uint32_t seg_len = (uint32_t)std::max<double>(
-        1.0, std::max(std::ceil(std::sqrt(per_bucket)), std::ceil((double)total / 1048576.0)));
+    const double fill = std::min(std::ceil((double)total / 262144.0),
+                                 std::max(32.0, std::ceil((double)total / 1048576.0)));
+    const uint32_t seg_len = (uint32_t)std::max<double>(1.0, std::max(std::ceil(std::sqrt(per_bucket)), fill));
     const size_t nseg = (total + seg_len - 1) / seg_len;
 
     size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
