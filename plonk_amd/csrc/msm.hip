@@ -477,12 +477,18 @@ MsmPlan msm_choose_plan(size_t srs_n, int override_bits) {
     int best = 0;
     if (override_bits >= 2 && override_bits <= 24) {
         best = override_bits;
+    } else if (srs_n > 1024) {
+        // Measured on MI355X.  Widths whose top window is narrow (255 mod c small) pile that
+        // window's digits into a few buckets and pay for it in the fix-up, hence 13, 16, 20, 22.
+        int lg = 0;
+        while (((size_t)1 << lg) < srs_n) lg++;
+        best = lg <= 16 ? 13 : (lg <= 20 ? 16 : (lg <= 23 ? 20 : 22));
     } else {
-        // Cost in "bucket additions": the accumulation runs ~2^18 lanes at once; the
+        // Small inputs: cost in "bucket additions"; the accumulation runs ~2^18 lanes at once, the
         // reduction is a serial tail whose depth grows with c.
         double best_cost = 1e300;
         const double lanes = 262144.0;
-        for (int c = 4; c <= 22; c++) {
+        for (int c = 4; c <= 13; c++) {
             double nwin = msm_num_windows(c);
             double nb = std::ldexp(1.0, c - 1);
             double total = (double)srs_n * nwin;
