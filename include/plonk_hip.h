@@ -147,7 +147,9 @@ int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_
  * 8 v_mad_u64_u32, 9 v_sub_u32): the per-instruction costs behind the kernels' instruction budgets. */
 int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
 /* Measured bytes/s of a random gather of whole 128-byte lines from a table of table_bytes: the
- * memory-side ceiling of the bucket accumulation's table reads. */
+ * memory-side ceiling of the bucket accumulation's table reads.  An odd table_bytes selects the
+ * access form the accumulation kernel uses (eight lanes per line, direct global-to-LDS loads);
+ * an even one the plain form (every lane reads its own line). */
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
 

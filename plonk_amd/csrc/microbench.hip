@@ -223,8 +223,47 @@ __global__ __launch_bounds__(128) void k_gather_rate(const uint4 *__restrict__ t
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
-// Bytes per second of that gather over a table of table_bytes (rounded down to whole lines).
+// The same gather in the form the bucket accumulation uses: the wave fetches its 64 lines with
+// eight direct global-to-LDS loads, eight lanes per line (pieces in swizzled order), and every lane
+// reads its own line back from LDS.
+__global__ __launch_bounds__(128) void k_gather_rate_coop(const uint4 *__restrict__ table, uint32_t lines, int iters,
+                                                         uint32_t seed, uint32_t *__restrict__ out) {
+    __shared__ uint4 line_buf[2][64 * 8];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void global_void_t;
+    const uint32_t lane = threadIdx.x & 63;
+    uint4 *buf = line_buf[threadIdx.x >> 6];
+    uint32_t h = seed ^ ((blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u);
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < iters; i++) {
+        h = h * 1664525u + 1013904223u;
+        uint32_t line = (uint32_t)(((uint64_t)(h ^ (h >> 15)) * lines) >> 32);
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++) {
+            const uint32_t owner = 8 * g + (lane >> 3);
+            const uint32_t idx = (uint32_t)__shfl((int)line, (int)owner, 64);
+            const uint32_t piece = (lane & 7) ^ (owner & 7);
+            __builtin_amdgcn_global_load_lds((global_void_t *)(table + (size_t)idx * 8 + piece),
+                                             (lds_void_t *)(buf + 64 * g), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            uint4 v = buf[8 * lane + (k ^ (lane & 7))];
+            acc.x ^= v.x;
+            acc.y += v.y;
+            acc.z ^= v.z;
+            acc.w += v.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
+// Bytes per second of that gather over a table of table_bytes (rounded down to whole lines);
+// table_bytes with its lowest bit set selects the cooperative form.
 int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
+    const bool coop = (table_bytes & 1) != 0;
     const uint32_t lines = (uint32_t)std::min<size_t>(table_bytes / 128, 0x7fffffffu);
     if (lines == 0) return PLONK_HIP_ERR_INVALID_ARG;
     const int blocks = 256 * 24, threads = 128, iters = 64;
@@ -237,9 +276,15 @@ int bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
         PLONK_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(k_gather_rate, dim3(blocks), dim3(threads), 0, ctx->stream,
-                           (const uint4 *)ctx->scratch_a.ptr, lines, iters, 0x51ed27u + rep,
-                           (uint32_t *)ctx->scratch_c.ptr);
+        if (coop) {
+            hipLaunchKernelGGL(k_gather_rate_coop, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (const uint4 *)ctx->scratch_a.ptr, lines, iters, 0x51ed27u + rep,
+                               (uint32_t *)ctx->scratch_c.ptr);
+        } else {
+            hipLaunchKernelGGL(k_gather_rate, dim3(blocks), dim3(threads), 0, ctx->stream,
+                               (const uint4 *)ctx->scratch_a.ptr, lines, iters, 0x51ed27u + rep,
+                               (uint32_t *)ctx->scratch_c.ptr);
+        }
         PLONK_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
         PLONK_HIP_TRY(ctx, hipEventSynchronize(e1));
         float ms = 0;

@@ -10,4 +10,6 @@ import plonk_amd
 be = plonk_amd.Backend(0)
 for gib in [float(x) for x in sys.argv[1:]] or [0.125, 2.0, 24.0]:
     r = be.bench_gather_rate(int(gib * (1 << 30)))
-    print("table %.3f GiB: %.1f GB/s" % (gib, r / 1e9), flush=True)
+    rc = be.bench_gather_rate(int(gib * (1 << 30)) | 1)
+    print("table %.3f GiB: %.1f GB/s lane-per-line, %.1f GB/s eight lanes per line through LDS" % (
+        gib, r / 1e9, rc / 1e9), flush=True)
