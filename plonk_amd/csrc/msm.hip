@@ -142,15 +142,24 @@ __device__ __forceinline__ G1Affine28 read_line(const uint4 *buf, uint32_t lane)
 // Two waves per SIMD: the whole addition then lives in registers.  A third wave (168 registers)
 // spills about 60 bytes per lane and iteration, which showed up as 13 GB of write traffic per
 // 2^24-point launch and cost more than the extra wave hid.
+//
+// STAGED (seg_len a multiple of 16): a lane's (bucket, entry) pairs come in through LDS sixteen
+// positions at a time (one 64-byte piece of each array per lane); fetched one position at a time
+// their cache lines are evicted and fetched again several times over a segment.
+static constexpr uint32_t kStage = 16;
+
+template <bool STAGED>
 __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                        uint32_t seg_len, const G1Affine28 *__restrict__ table,
                                                        G1Xyzz28 *__restrict__ buckets,
                                                        G1Xyzz28 *__restrict__ part) {
-    __shared__ uint4 line_buf[kBlock / 64][64 * 8];  // 8 KiB per wave
+    __shared__ uint4 line_buf[kBlock / 64][64 * 8];                           // 8 KiB per wave
+    __shared__ uint32_t pair_buf[STAGED ? kBlock / 64 : 1][2][kStage][64];   // 8 KiB per wave
     const uint32_t lane = threadIdx.x & 63;
     uint4 *buf = line_buf[threadIdx.x >> 6];
+    uint32_t(*pairs)[kStage][64] = pair_buf[STAGED ? threadIdx.x >> 6 : 0];
     const size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nvalid = start[nbuckets];
     const size_t begin64 = seg * seg_len;
@@ -161,32 +170,71 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     const size_t end64 = begin64 + seg_len;
     const uint32_t end = live ? (end64 < nvalid ? (uint32_t)end64 : nvalid) : 0u;
 
+    // sixteen positions of both arrays, global memory -> registers -> LDS
+    uint4 ck[4], cv[4];
+    auto chunk_load = [&](uint32_t first) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ck[q] = make_uint4(0, 0, 0, 0);
+            cv[q] = make_uint4(0, 0, 0, 0);
+            if (first < end) {
+                ck[q] = reinterpret_cast<const uint4 *>(keys + first)[q];
+                cv[q] = reinterpret_cast<const uint4 *>(vals + first)[q];
+            }
+        }
+    };
+    auto chunk_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pairs[0][4 * q + 0][lane] = ck[q].x;
+            pairs[0][4 * q + 1][lane] = ck[q].y;
+            pairs[0][4 * q + 2][lane] = ck[q].z;
+            pairs[0][4 * q + 3][lane] = ck[q].w;
+            pairs[1][4 * q + 0][lane] = cv[q].x;
+            pairs[1][4 * q + 1][lane] = cv[q].y;
+            pairs[1][4 * q + 2][lane] = cv[q].z;
+            pairs[1][4 * q + 3][lane] = cv[q].w;
+        }
+    };
+    // pair at position begin + o (zeros behind the segment's end)
+    auto pair_at = [&](uint32_t o, uint32_t &key, uint32_t &val) {
+        key = 0;
+        val = 0;
+        if (begin + o < end) {
+            if (STAGED) {
+                key = pairs[0][o & (kStage - 1)][lane];
+                val = pairs[1][o & (kStage - 1)][lane];
+            } else {
+                key = keys[begin + o];
+                val = vals[begin + o];
+            }
+        }
+    };
+
     // (bucket, entry) of the current position and of the next one; the line of the current
     // position is always on its way to (or in) the wave's buffer
-    uint32_t k = 0, v = 0, kn = 0, vn = 0;
-    if (begin < end) {
-        k = keys[begin];
-        v = vals[begin];
+    if (STAGED) {
+        chunk_load(begin);
+        chunk_store();
     }
-    if (begin + 1 < end) {
-        kn = keys[begin + 1];
-        vn = vals[begin + 1];
-    }
+    uint32_t k, v, kn, vn;
+    pair_at(0, k, v);
+    pair_at(1, kn, vn);
     issue_lines(table, buf, lane, v & 0x7fffffffu);
     uint32_t cur = k;
     uint32_t run_begin = begin;
     G1Xyzz28 acc = xyzz28_identity();
+    bool staged_pending = false;
     for (uint32_t it = 0; it < seg_len; it++) {  // the same trip count for every lane of the grid
         const uint32_t p = begin + it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this position's lines have landed
+        // the pairs at positions it and it + 1 are in registers: the staged sixteen can be replaced
+        if (STAGED && staged_pending) chunk_store();
         G1Affine28 pt = read_line(buf, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane holds its line: the buffer is free
         issue_lines(table, buf, lane, vn & 0x7fffffffu);
-        uint32_t k2 = 0, v2 = 0;
-        if (p + 2 < end) {
-            k2 = keys[p + 2];
-            v2 = vals[p + 2];
-        }
+        uint32_t k2, v2;
+        pair_at(it + 2, k2, v2);
         if (p < end) {
             if (k != cur) {
                 flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
@@ -211,6 +259,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         v = vn;
         kn = k2;
         vn = v2;
+        // the next iteration reads position it + 3: fetch its sixteen now if it opens a new group
+        // (the loads complete with the wait at the top of the loop)
+        staged_pending = STAGED && ((it + 3) & (kStage - 1)) == 0 && it + 3 < seg_len;
+        if (staged_pending) chunk_load(begin + it + 3);
     }
     if (live) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
 }
@@ -543,14 +595,15 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     const double per_bucket = (double)total / nb;
     const double fill = std::min(std::ceil((double)total / 262144.0),
                                  std::max(32.0, std::ceil((double)total / 1048576.0)));
-    const uint32_t seg_len = (uint32_t)std::max<double>(1.0, std::max(std::ceil(std::sqrt(per_bucket)), fill));
+    uint32_t seg_len = (uint32_t)std::max<double>(1.0, std::max(std::ceil(std::sqrt(per_bucket)), fill));
+    if (seg_len >= 32) seg_len = (seg_len + kStage - 1) / kStage * kStage;  // staged pair loads need whole groups
     const size_t nseg = (total + seg_len - 1) / seg_len;
 
     size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
-    PLONK_TRY(buf_reserve(ctx, ctx->keys_a, total * 4));
-    PLONK_TRY(buf_reserve(ctx, ctx->keys_b, total * 4));
-    PLONK_TRY(buf_reserve(ctx, ctx->vals_a, total * 4));
-    PLONK_TRY(buf_reserve(ctx, ctx->vals_b, total * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_a, (total + kStage) * 4));  // staged loads read whole groups
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_b, (total + kStage) * 4));  // staged loads read whole groups
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + kStage) * 4));  // staged loads read whole groups
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
     PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
@@ -591,8 +644,13 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, per_lane << g_log,
                        big_count, big_list);
     record(ctx, PH_ACCUM);
-    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
-                       seg_len, table, buckets, part);
+    if (seg_len % kStage == 0) {
+        hipLaunchKernelGGL(k_accumulate<true>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
+                           seg_len, table, buckets, part);
+    } else {
+        hipLaunchKernelGGL(k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start,
+                           nb, seg_len, table, buckets, part);
+    }
     record(ctx, PH_FIXUP);
     hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, st, start, nb, seg_len, part,
                        buckets, g_log, per_lane, group_blocks, big_count, big_list);
