@@ -108,6 +108,40 @@ def test_commit_edge_scalars_and_points(backend):
     assert compress(backend.kzg_commit(c.fr_to_mont(cases["zeros"]))) == o.g1_compress(o.G1_IDENTITY)
 
 
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_commit_skewed_buckets_known_answer(backend, log_n):
+    # every scalar equal (all points of a window land in one bucket), all r - 1, one in sixteen zero:
+    # commit(f) == [f(tau)] G  (plonk/tests/kzg_tests.rs:36-69)
+    rnd = random.Random(6 + log_n)
+    n = 1 << log_n
+    g = c.g1_generator()
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    s = rnd.randrange(o.R)
+    cases = {
+        "equal": [s] * n,
+        "minus_one": [o.R - 1] * n,
+        "sparse": [rnd.randrange(o.R) if i % 16 else 0 for i in range(n)],
+        "two_values": [s if i % 3 else 5 for i in range(n)],
+    }
+    for name, vals in cases.items():
+        sc = c.fr_to_mont(vals)
+        assert same_point(backend.kzg_commit(sc), c.g1_mul(g, c.fr_eval(sc, tau))), name
+
+
+def test_commit_when_every_srs_point_is_the_generator(backend):
+    # tau = 1: all points equal, so additions inside a bucket keep meeting equal operands (the
+    # doubling path of the accumulation and of the tree sums); commit(f) == [sum f_i] G
+    rnd = random.Random(8)
+    n = 1 << 12
+    g = c.g1_generator()
+    backend.kzg_setup(c.fr_to_mont([1])[0], n - 1, want_points=False)
+    for vals in ([1] * n, [rnd.randrange(o.R)] * n, rand_fr(rnd, n), [rnd.randrange(8) for _ in range(n)]):
+        sc = c.fr_to_mont(vals)
+        total = c.fr_to_mont([sum(vals) % o.R])[0]
+        assert same_point(backend.kzg_commit(sc), c.g1_mul(g, total))
+
+
 def test_open_matches_reference_definition(backend):
     rnd = random.Random(4)
     for n in (2, 3, 65, 300, 5000):
