@@ -56,6 +56,7 @@ struct plonk_hip_ctx {
     plonk::DevBuf gen_table;
     // twiddles for the NTT: per log_n forward and inverse tables
     plonk::DevBuf twiddle[2][33];
+    bool ntt_lds_opt_in = false;  // large dynamic LDS enabled for the transform kernels on this device
 
     bool profile = false;
     hipEvent_t ev[plonk::PH_COUNT + 1] = {};

@@ -416,15 +416,6 @@ __global__ __launch_bounds__(256) void k_mul_halves(Fr *__restrict__ data, size_
     *q = fe_mul(*q, p < n / 2 ? lo_half : hi_half);
 }
 
-// stages kept in registers per LDS round trip (experiment switch: PLONK_NTT_G=2|3)
-static int ntt_gmax() {
-    static int g = [] {
-        const char *e = getenv("PLONK_NTT_G");
-        return (e && e[0] == '2') ? 2 : 3;
-    }();
-    return g;
-}
-
 static constexpr int kMaxTileLog = 11;  // 2048 elements = 74 KiB of LDS
 
 struct PassPlan {
@@ -509,18 +500,14 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     Fr29 sc = scale ? fr29_twiddle_from(*scale) : Fr29{};
     Fr29 sc_up = scale_upper ? fr29_twiddle_from(*scale_upper) : Fr29{};
     const int scale_mode = scale_upper ? 2 : 1;
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS
+    if (!ctx->ntt_lds_opt_in) {
+        // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS (set once per
+        // context, i.e. per device)
         PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true, 3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false, 3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<true, 2>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        PLONK_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_ntt_pass<false, 2>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        lds_opt_in = true;
+        ctx->ntt_lds_opt_in = true;
     }
     for (int q = 0; q < pl.npass; q++) {
         int i = dif ? pl.npass - 1 - q : q;
@@ -535,8 +522,7 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         if ((n >> k) < ((size_t)1 << tpb_log)) tpb_log = (uint32_t)(log_n - k);
         const uint32_t tile_n = 1u << k;
         const size_t lds = (size_t)(9 * tile_n + (tile_n >> 5) + 1) * 4 << tpb_log;
-        const int gmax = ntt_gmax();
-        const unsigned threads = gmax == 2 ? 256 : (k + tpb_log >= 11 ? 256 : 128);
+        const unsigned threads = k + tpb_log >= 11 ? 256 : 128;
         dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
         const int sm = (last && scale) ? scale_mode : 0, canon = last ? 1 : 0;
         // natural order: DIF = strided pass (rows stored reversed) then the s0 = 0 pass (scattered
@@ -554,10 +540,11 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
 #define PLONK_LAUNCH_PASS(DIFV, G)                                                                               \
     hipLaunchKernelGGL((k_ntt_pass<DIFV, G>), grid, dim3(threads), lds, ctx->stream, src, dst, log_n, pl.s0[i],    \
                        pl.s1[i], tpb_log, tw, n, sc, sc_up, sm, canon, in_map, out_map)
+        // (a two-stage variant, GMAX = 2, runs four waves per SIMD at the same speed)
         if (dif) {
-            if (gmax == 2) PLONK_LAUNCH_PASS(true, 2); else PLONK_LAUNCH_PASS(true, 3);
+            PLONK_LAUNCH_PASS(true, 3);
         } else {
-            if (gmax == 2) PLONK_LAUNCH_PASS(false, 2); else PLONK_LAUNCH_PASS(false, 3);
+            PLONK_LAUNCH_PASS(false, 3);
         }
 #undef PLONK_LAUNCH_PASS
     }
