@@ -52,7 +52,10 @@ enum {
     PLONK_HIP_ERR_NO_SRS = -5,
     PLONK_HIP_ERR_HIP = -6,         /* a HIP runtime call failed; see plonk_hip_last_error() */
     PLONK_HIP_ERR_OUT_OF_MEMORY = -7,
-    PLONK_HIP_ERR_NOT_DIVISIBLE = -8 /* coset quotient asked for a polynomial Z_Omega does not divide */
+    PLONK_HIP_ERR_NOT_DIVISIBLE = -8, /* coset quotient asked for a polynomial Z_Omega does not divide */
+    /* a compressed G1 encoding that `G1::deserialize_compressed` rejects; the reference panics on
+     * `.expect("Failed to deserialize G1")` (plonk/src/setup_global_params/json.rs:30-33) */
+    PLONK_HIP_ERR_INVALID_POINT = -9
 };
 
 /* ----------------------------------------------------------------------------------------
@@ -85,6 +88,21 @@ int plonk_hip_srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts /* n x
 int plonk_hip_srs_size(plonk_hip_ctx *ctx, size_t *n);
 /* Reads back SRS points [first, first+count) as Jacobian triples with Z = 1. */
 int plonk_hip_srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out /* count x 18 */);
+
+/* The SRS from its compressed encodings, as `SetupGlobalParamsOutputJson::into_setup_output` reads
+ * it (plonk/src/setup_global_params/json.rs:22-48: hex -> 48 bytes -> `G1::deserialize_compressed`;
+ * the hex step stays with the caller).  bytes = n x 48.  check_subgroup != 0 validates like the
+ * reference does (on the curve and in the prime-order subgroup); 0 skips the subgroup test for
+ * trusted files.  On PLONK_HIP_ERR_INVALID_POINT *bad_index (may be NULL) is the first rejected
+ * entry and the context holds no SRS. */
+int plonk_hip_srs_load_compressed(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, int check_subgroup,
+                                  size_t *bad_index);
+/* Batch forms of `G1::deserialize_compressed` / `serialize_compressed` (json.rs:30-33;
+ * plonk/src/common/utils.rs:70-72, plonk/src/common/proof.rs:58-268): n x 48 bytes <-> n x 18 limbs
+ * (decoded points have Z = 1; the identity is (1, 1, 0)). */
+int plonk_hip_g1_decompress(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, int check_subgroup,
+                            uint64_t *out_pts /* n x 18 */, size_t *bad_index);
+int plonk_hip_g1_compress(plonk_hip_ctx *ctx, const uint64_t *pts /* n x 18 */, size_t n, uint8_t *bytes);
 
 /* `kzg_setup(degree)` (kzg.rs:24-45) with tau supplied by the caller: computes [tau^i]G for
  * i = 0..degree on the GPU, installs the result as the context's SRS and, if out_pts is not

@@ -11,6 +11,7 @@ from . import lib as _l
 ERR_SRS_TOO_SHORT = -1
 ERR_EMPTY_POLY = -2
 ERR_ZERO_DENOMINATOR = -3
+ERR_INVALID_POINT = -9
 
 
 class PlonkHipError(RuntimeError):
@@ -68,7 +69,7 @@ class Backend:
             text += " (" + detail + ")"
         if rc == ERR_SRS_TOO_SHORT:
             raise CommitError(rc, text)
-        if rc in (ERR_EMPTY_POLY, ERR_ZERO_DENOMINATOR):
+        if rc in (ERR_EMPTY_POLY, ERR_ZERO_DENOMINATOR, ERR_INVALID_POINT):
             raise ReferencePanic(rc, text)
         raise PlonkHipError(rc, text)
 
@@ -151,6 +152,37 @@ class Backend:
         """`GlobalParameters.tau_powers_g1` (kzg.rs:17-21): (n, 18) Jacobian limbs."""
         pts = _fr(pts, 18)
         self._check(self._lib.plonk_hip_srs_load_projective(self._ctx, _u64(pts), pts.shape[0]))
+
+    def srs_load_compressed(self, encodings, check_subgroup=True):
+        """The SRS as setup_global_params/json.rs:22-48 reads it: an iterable of 48-byte compressed
+        G1 encodings (or one bytes object of n x 48).  Raises ReferencePanic on an encoding that
+        `G1::deserialize_compressed` rejects."""
+        raw = encodings if isinstance(encodings, (bytes, bytearray)) else b"".join(encodings)
+        assert len(raw) % 48 == 0
+        bad = ctypes.c_size_t()
+        self._check(self._lib.plonk_hip_srs_load_compressed(self._ctx, bytes(raw), len(raw) // 48,
+                                                            1 if check_subgroup else 0, ctypes.byref(bad)))
+
+    def g1_decompress(self, encodings, check_subgroup=True):
+        """Batch `G1::deserialize_compressed`: -> (n, 18) Jacobian limbs (Z = 1; identity (1, 1, 0))."""
+        raw = encodings if isinstance(encodings, (bytes, bytearray)) else b"".join(encodings)
+        assert len(raw) % 48 == 0
+        n = len(raw) // 48
+        out = np.empty((n, 18), dtype=np.uint64)
+        bad = ctypes.c_size_t()
+        rc = self._lib.plonk_hip_g1_decompress(self._ctx, bytes(raw), n, 1 if check_subgroup else 0, _u64(out),
+                                               ctypes.byref(bad))
+        self.last_bad_index = bad.value
+        self._check(rc)
+        return out
+
+    def g1_compress(self, pts):
+        """Batch `serialize_compressed` (utils.rs:70-72): (n, 18) limbs -> list of 48-byte strings."""
+        pts = _fr(pts, 18)
+        n = pts.shape[0]
+        buf = ctypes.create_string_buffer(48 * n)
+        self._check(self._lib.plonk_hip_g1_compress(self._ctx, _u64(pts), n, buf))
+        return [buf.raw[48 * i:48 * i + 48] for i in range(n)]
 
     def srs_size(self):
         n = ctypes.c_size_t()

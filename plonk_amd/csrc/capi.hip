@@ -106,6 +106,7 @@ const char *plonk_hip_strerror(int code) {
         case PLONK_HIP_ERR_HIP: return "HIP runtime error";
         case PLONK_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
         case PLONK_HIP_ERR_NOT_DIVISIBLE: return "polynomial is not divisible by the vanishing polynomial";
+        case PLONK_HIP_ERR_INVALID_POINT: return "Failed to deserialize G1";
         default: return "unknown error";
     }
 }
@@ -158,6 +159,42 @@ int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev
 int plonk_hip_srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
     PLONK_ENTER(ctx);
     return srs_load_projective(ctx, pts, n);
+}
+
+int plonk_hip_srs_load_compressed(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, int check_subgroup,
+                                  size_t *bad_index) {
+    PLONK_ENTER(ctx);
+    return srs_load_compressed(ctx, bytes, n, check_subgroup != 0, bad_index);
+}
+
+int plonk_hip_g1_decompress(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, int check_subgroup, uint64_t *out_pts,
+                            size_t *bad_index) {
+    PLONK_ENTER(ctx);
+    if ((!bytes || !out_pts) && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * 48));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * sizeof(G1Affine)));
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, n * sizeof(G1Jac)));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(ctx->scalars_stage.ptr, bytes, n * 48, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(g1_decompress_dev(ctx, (const uint8_t *)ctx->scalars_stage.ptr, n, check_subgroup != 0,
+                                (G1Affine *)ctx->scratch_c.ptr, bad_index));
+    PLONK_TRY(g1_affine_to_jac_dev(ctx, (const G1Affine *)ctx->scratch_c.ptr, n, (G1Jac *)ctx->stage_c.ptr));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(out_pts, ctx->stage_c.ptr, n * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_g1_compress(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n, uint8_t *bytes) {
+    PLONK_ENTER(ctx);
+    if ((!pts || !bytes) && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->stage_c, n * sizeof(G1Jac)));
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * 48));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.ptr, pts, n * sizeof(G1Jac), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(g1_compress_dev(ctx, (const G1Jac *)ctx->stage_c.ptr, n, (uint8_t *)ctx->scalars_stage.ptr));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(bytes, ctx->scalars_stage.ptr, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
 }
 
 int plonk_hip_srs_size(plonk_hip_ctx *ctx, size_t *n) {

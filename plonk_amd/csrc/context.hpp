@@ -108,5 +108,12 @@ int srs_install_affine(plonk_hip_ctx *ctx, size_t n);  // level 0 already in ctx
 int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n);
 int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t n, uint64_t *out_pts);
 int srs_read(plonk_hip_ctx *ctx, size_t first, size_t count, uint64_t *out);
+int srs_load_compressed(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, bool check_subgroup, size_t *bad_index);
+
+// codec.hip
+int g1_decompress_dev(plonk_hip_ctx *ctx, const uint8_t *d_bytes, size_t n, bool check_subgroup, G1Affine *d_affine,
+                      size_t *bad_index);
+int g1_affine_to_jac_dev(plonk_hip_ctx *ctx, const G1Affine *d_affine, size_t n, G1Jac *d_out);
+int g1_compress_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, uint8_t *d_bytes);
 
 }  // namespace plonk

@@ -208,6 +208,18 @@ int srs_load_projective(plonk_hip_ctx *ctx, const uint64_t *pts, size_t n) {
     return srs_build_levels(ctx, n);
 }
 
+// SRS from its compressed encodings (n x 48 bytes in host memory), decoded and validated on the
+// device.  On a rejected encoding the context is left without an SRS.
+int srs_load_compressed(plonk_hip_ctx *ctx, const uint8_t *bytes, size_t n, bool check_subgroup, size_t *bad_index) {
+    if (!bytes) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_TRY(srs_begin(ctx, n));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_a, n * sizeof(G1Jac)));  // also the work area of srs_build_levels
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.ptr, bytes, n * 48, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(g1_decompress_dev(ctx, (const uint8_t *)ctx->scratch_a.ptr, n, check_subgroup,
+                                (G1Affine *)ctx->level_a.ptr, bad_index));
+    return srs_build_levels(ctx, n);
+}
+
 int srs_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t first, size_t n, uint64_t *out_pts) {
     if (!tau || n == 0) return PLONK_HIP_ERR_INVALID_ARG;
     if (n >= 0xffffffffull) return PLONK_HIP_ERR_INVALID_ARG;

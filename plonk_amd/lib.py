@@ -63,6 +63,11 @@ SIGNATURES = {
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint32, ctypes.c_size_t, c_u64p, c_intp]),
     "plonk_hip_fr_quotient_coset_dev": (
         ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, c_intp]),
+    "plonk_hip_srs_load_compressed": (
+        ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    "plonk_hip_g1_decompress": (
+        ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, c_u64p, ctypes.POINTER(ctypes.c_size_t)]),
+    "plonk_hip_g1_compress": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_char_p]),
     "plonk_hip_bench_op_rate": (ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_gather_rate": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_fr_eval_many": (
