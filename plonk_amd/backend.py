@@ -182,7 +182,8 @@ class Backend:
         n = pts.shape[0]
         buf = ctypes.create_string_buffer(48 * n)
         self._check(self._lib.plonk_hip_g1_compress(self._ctx, _u64(pts), n, buf))
-        return [buf.raw[48 * i:48 * i + 48] for i in range(n)]
+        raw = buf.raw  # one copy
+        return [raw[48 * i:48 * i + 48] for i in range(n)]
 
     def srs_size(self):
         n = ctypes.c_size_t()
