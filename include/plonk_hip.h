@@ -183,6 +183,11 @@ int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_
  *                (plonk/src/common/polynomials.rs:50-58), zero padded to 2^log_n. */
 int plonk_hip_fr_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, int inverse);
 int plonk_hip_fr_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch, int inverse);
+/* The same over Omega = construct_Omega(n) for n = 2^k or 3 * 2^k (the reference's domains have
+ * 3 points per gate, plonk/src/setup_global_params/mod.rs:57; its example circuit has n = 12):
+ * one radix-3 step around the power-of-two transform.  PLONK_HIP_ERR_INVALID_ARG for other n. */
+int plonk_hip_fr_ntt_mixed(plonk_hip_ctx *ctx, uint64_t *data, size_t n, size_t batch, int inverse);
+int plonk_hip_fr_ntt_mixed_dev(plonk_hip_ctx *ctx, void *d_data, size_t n, size_t batch, int inverse);
 /* The same over the coset shift * Omega: forward evaluates f at shift*omega^j, inverse
  * interpolates from those values. */
 int plonk_hip_fr_coset_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, size_t batch, const uint64_t shift[4],

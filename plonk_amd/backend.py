@@ -269,6 +269,15 @@ class Backend:
         self._check(rc)
         return d.reshape(shape)
 
+    def fr_ntt_mixed(self, data, inverse=False):
+        """Evaluations over / interpolation from construct_Omega(n), n = 2^k or 3 * 2^k; natural
+        order.  data: (batch, n, 4) or (n, 4).  Returns a new array."""
+        d = np.array(data, dtype=np.uint64)
+        shape = d.shape
+        d = d.reshape(-1, shape[-2], 4) if d.ndim == 3 else d.reshape(1, -1, 4)
+        self._check(self._lib.plonk_hip_fr_ntt_mixed(self._ctx, _u64(d), d.shape[1], d.shape[0], 1 if inverse else 0))
+        return d.reshape(shape)
+
     def fr_ntt_dev(self, dptr, log_n, batch, inverse=False):
         self._check(self._lib.plonk_hip_fr_ntt_dev(self._ctx, dptr, log_n, batch, 1 if inverse else 0))
 

@@ -84,7 +84,7 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
                       &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
                       &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b,
-                      &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws};
+                      &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws, &ctx->ntt3_ws};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
         for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
@@ -445,6 +445,26 @@ int plonk_hip_fr_coset_ntt(plonk_hip_ctx *ctx, uint64_t *data, uint32_t log_n, s
                            int inverse) {
     if (!shift) return PLONK_HIP_ERR_INVALID_ARG;
     return ntt_host(ctx, data, log_n, batch, shift, inverse);
+}
+
+int plonk_hip_fr_ntt_mixed(plonk_hip_ctx *ctx, uint64_t *data, size_t n, size_t batch, int inverse) {
+    PLONK_ENTER(ctx);
+    if (!data && n * batch) return PLONK_HIP_ERR_INVALID_ARG;
+    size_t total = n * batch;
+    if (total == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, total * sizeof(Fr)));
+    Fr *d = (Fr *)ctx->scratch_c.ptr;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(d, data, total * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(ntt_mixed_dev(ctx, d, n, batch, inverse != 0));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(data, d, total * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_ntt_mixed_dev(plonk_hip_ctx *ctx, void *d_data, size_t n, size_t batch, int inverse) {
+    PLONK_ENTER(ctx);
+    if (!d_data) return PLONK_HIP_ERR_INVALID_ARG;
+    return ntt_mixed_dev(ctx, (Fr *)d_data, n, batch, inverse != 0);
 }
 
 int plonk_hip_fr_ntt_dev(plonk_hip_ctx *ctx, void *d_data, uint32_t log_n, size_t batch, int inverse) {

@@ -49,7 +49,7 @@ struct plonk_hip_ctx {
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
     // workspaces of the polynomial product, product tree, series division and interpolation
-    plonk::DevBuf mul_ws, tree_ws, div_ws, interp_ws, ntt_ws;
+    plonk::DevBuf mul_ws, tree_ws, div_ws, interp_ws, ntt_ws, ntt3_ws;
     // two levels of the SRS in 12 x 32-bit affine form while the window tables are being built
     plonk::DevBuf level_a, level_b;
     // fixed-base table of the generator for kzg_setup (32 windows x 256 affine multiples)

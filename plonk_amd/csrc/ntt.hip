@@ -596,6 +596,86 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
 }
 
 // ------------------------------------------------------------------------------------------
+// domains of size 3 * 2^k (the reference lays a circuit of G gates out on 3G + ... points:
+// setup_global_params/mod.rs:57; its example uses d = 12): one radix-3 step around the
+// power-of-two transform
+// ------------------------------------------------------------------------------------------
+// omega_n = 7^((r-1)/n) for any n dividing r - 1 (common/utils.rs:11-38); false when n does not
+static bool fr_root_of_unity_general(uint64_t n, Fr *out) {
+    if (n == 0 || n > 0xffffffffull) return false;
+    uint32_t e[8];
+    for (int i = 0; i < 8; i++) e[i] = FrCfg::mod(i);
+    e[0] -= 1;
+    uint64_t rem = 0;
+    for (int i = 7; i >= 0; i--) {  // (r - 1) / n by long division on 32-bit limbs
+        uint64_t cur = (rem << 32) | e[i];
+        e[i] = (uint32_t)(cur / n);
+        rem = cur % n;
+    }
+    if (rem != 0) return false;
+    Fr base = fr_from_u64(7), acc = fe_one<FrCfg>();
+    for (int i = 7; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            acc = fe_sqr(acc);
+            if ((e[i] >> b) & 1) acc = fe_mul(acc, base);
+        }
+    *out = acc;
+    return true;
+}
+
+// y[c][i] = x[3 i + c]
+__global__ __launch_bounds__(256) void k_deinterleave3(const Fr *__restrict__ x, size_t m, Fr *__restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * m) return;
+    const Fr *src = x + (size_t)blockIdx.y * 3 * m;
+    Fr *dst = y + (size_t)blockIdx.y * 3 * m;
+    dst[(i % 3) * m + i / 3] = src[i];
+}
+// X[j] = (Y0[j mod m] + w^j Y1[j mod m] + w^2j Y2[j mod m]) * scale, w^j = lo[j & 1023] * hi[j >> 10]
+__global__ __launch_bounds__(256) void k_combine3(const Fr *__restrict__ y, size_t m, const Fr *__restrict__ lo,
+                                                 const Fr *__restrict__ hi, Fr scale, int do_scale,
+                                                 Fr *__restrict__ x) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 3 * m) return;
+    const Fr *src = y + (size_t)blockIdx.y * 3 * m;
+    Fr w = lo[j & 1023];
+    if (j >> 10) w = fe_mul(w, hi[j >> 10]);
+    const size_t i = j % m;
+    Fr acc = fe_add(src[i], fe_mul(w, fe_add(src[m + i], fe_mul(w, src[2 * m + i]))));
+    if (do_scale) acc = fe_mul(acc, scale);
+    x[(size_t)blockIdx.y * 3 * m + j] = acc;
+}
+
+// Natural order in and out over Omega = construct_Omega(n), n = 2^k or 3 * 2^k.
+int ntt_mixed_dev(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, bool inverse) {
+    if (n == 0 || batch == 0) return PLONK_HIP_OK;
+    size_t m = n;
+    uint32_t log_m = 0;
+    while ((m & 1) == 0) {
+        m >>= 1;
+        log_m++;
+    }
+    if (m == 1) return ntt_dev(ctx, d_data, log_m, batch, inverse, nullptr);
+    if (m != 3 || log_m > 29 || batch * 3 > 65535) return PLONK_HIP_ERR_INVALID_ARG;
+    m = (size_t)1 << log_m;
+    Fr w;
+    if (!fr_root_of_unity_general(n, &w)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (inverse) w = fe_inv(w);
+    PLONK_TRY(buf_reserve(ctx, ctx->ntt3_ws, batch * n * sizeof(Fr)));
+    Fr *y = (Fr *)ctx->ntt3_ws.ptr;
+    hipLaunchKernelGGL(k_deinterleave3, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, m, y);
+    // the three sub-transforms use omega_n^3 = omega_m (the inverse ones also divide by m)
+    PLONK_TRY(ntt_dev(ctx, y, log_m, batch * 3, inverse, nullptr));
+    const Fr *lo, *hi;
+    PLONK_TRY(build_two_level(ctx, w, n, &lo, &hi));
+    const Fr third = fe_inv(fr_from_u64(3));
+    hipLaunchKernelGGL(k_combine3, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, y, m, lo, hi, third,
+                       inverse ? 1 : 0, d_data);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // coset quotient by X^k - 1
 // ------------------------------------------------------------------------------------------
 __global__ void k_set_int(int *__restrict__ flags, size_t count, int value) {

@@ -70,6 +70,9 @@ SIGNATURES = {
     "plonk_hip_g1_compress": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_char_p]),
     "plonk_hip_bench_op_rate": (ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_gather_rate": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]),
+    "plonk_hip_fr_ntt_mixed": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),
+    "plonk_hip_fr_ntt_mixed_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),
     "plonk_hip_fr_eval_many": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_evaluate_over_omega": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_uint32, c_u64p]),

@@ -5,6 +5,8 @@ import random
 import numpy as np
 import pytest
 
+import plonk_amd
+
 from oracle import capi as c
 from oracle import pyref as o
 from tests.gpu_util import backend, rand_fr  # noqa: F401
@@ -129,3 +131,30 @@ def test_quotient_coset(backend, log_k):
     for b in range(2):
         assert c.fr_from_mont(q[b]) == qs[b]
         assert o.poly_trim(qs[b]) == o.compute_q_zero_test(k, fs[b])
+
+
+@pytest.mark.parametrize("n", [3, 6, 12, 24, 96, 3 << 10, 1 << 6])
+def test_ntt_over_domains_of_size_3_times_a_power_of_two(backend, n):
+    # the reference's domains hold three points per gate (setup_global_params/mod.rs:57); the
+    # example circuit's Omega has 12 elements (utils.rs:11-38 with k = 12)
+    rnd = random.Random(80 + n)
+    batch = 2
+    co = [rand_fr(rnd, n) for _ in range(batch)]
+    data = c.fr_to_mont([x for row in co for x in row]).reshape(batch, n, 4)
+    ev = backend.fr_ntt_mixed(data)
+    Om = o.construct_Omega(n)
+    idx = range(n) if n <= 24 else rnd.sample(range(n), 12)
+    for b in range(batch):
+        got = c.fr_from_mont(ev[b])
+        for j in idx:
+            assert got[j] == o.poly_eval(co[b], Om[j])
+    assert np.array_equal(backend.fr_ntt_mixed(ev, inverse=True), data)
+    if n == 12:
+        ys = rand_fr(rnd, n)
+        coeffs = c.fr_from_mont(backend.fr_ntt_mixed(c.fr_to_mont(ys), inverse=True))
+        assert o.poly_trim(coeffs) == o.interpolate_polynomial(Om, ys)  # polynomials.rs:50-58
+
+
+def test_ntt_mixed_rejects_other_sizes(backend):
+    with pytest.raises(plonk_amd.PlonkHipError):
+        backend.fr_ntt_mixed(np.zeros((10, 4), dtype=np.uint64))
