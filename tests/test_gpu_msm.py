@@ -222,3 +222,15 @@ def test_commit_2_24_points_known_answer(backend):
     assert same_point(backend.from_device(d_out, (18,)), got)
     backend.free(d_parts)
     backend.free(d_out)
+
+
+def test_commit_2_26_points_known_answer(backend):
+    # the largest size whose 12 window tables (96 GiB) fit beside the work buffers in 288 GB
+    n = 1 << 26
+    tau = c.fr_to_mont([0x7654321 + (1 << 190)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    rng = np.random.default_rng(26)
+    sc = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    got = backend.kzg_commit(sc)
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
