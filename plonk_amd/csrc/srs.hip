@@ -9,7 +9,7 @@
 
 namespace plonk {
 
-static constexpr int kBatch = 16;  // points per lane in the shared-inversion normalisation
+static constexpr int kBatch = 64;  // points per lane in the shared-inversion normalisation
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
