@@ -170,6 +170,12 @@ int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
  * an even one the plain form (every lane reads its own line). */
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
+/* Host-only planning, usable without a GPU: the window plan an SRS of srs_n points would get, and
+ * the passes of a 2^log_n-point transform (returns the number of passes, stage ranges
+ * [first_stage[i], end_stage[i]) in ascending order; 0 for sizes below 8, which take no tiled pass). */
+int plonk_hip_msm_plan_for(size_t srs_n, int window_bits_override, int *window_bits, int *windows, size_t *buckets);
+int plonk_hip_ntt_plan(uint32_t log_n, int natural_order, int max_passes, uint32_t *first_stage,
+                       uint32_t *end_stage);
 
 /* ----------------------------------------------------------------------------------------
  * Polynomials over Fr

@@ -363,6 +363,21 @@ const char *plonk_hip_msm_phase_name(int i) {
     return (i >= 0 && i < PH_COUNT) ? names[i] : "";
 }
 
+int plonk_hip_msm_plan_for(size_t srs_n, int window_bits_override, int *window_bits, int *windows, size_t *buckets) {
+    if (srs_n == 0) return PLONK_HIP_ERR_INVALID_ARG;
+    MsmPlan pl = msm_choose_plan(srs_n, window_bits_override);
+    if (window_bits) *window_bits = pl.c;
+    if (windows) *windows = pl.nwin;
+    if (buckets) *buckets = pl.nbuckets;
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_ntt_plan(uint32_t log_n, int natural_order, int max_passes, uint32_t *first_stage,
+                       uint32_t *end_stage) {
+    if (!first_stage || !end_stage || max_passes < 1) return PLONK_HIP_ERR_INVALID_ARG;
+    return ntt_plan_describe(log_n, natural_order != 0, max_passes, first_stage, end_stage);
+}
+
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets) {
     if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;

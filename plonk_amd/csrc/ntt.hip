@@ -551,6 +551,25 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     return PLONK_HIP_OK;
 }
 
+// The pass structure of a transform of 2^log_n points, for inspection: stage ranges [s0, s1) in
+// ascending order of s0.  natural: the two-pass form with the permutation folded in.
+int ntt_plan_describe(uint32_t log_n, bool natural, int max_passes, uint32_t *s0, uint32_t *s1) {
+    if (log_n < 3 || log_n > 30) return 0;
+    PassPlan pl = make_plan(log_n);
+    if (natural && log_n <= kMaxNaturalLog && log_n > (uint32_t)kMaxTileLog) {
+        pl.npass = 2;
+        pl.s0[0] = 0;
+        pl.s1[0] = log_n / 2;
+        pl.s0[1] = log_n / 2;
+        pl.s1[1] = log_n;
+    }
+    for (int i = 0; i < pl.npass && i < max_passes; i++) {
+        s0[i] = pl.s0[i];
+        s1[i] = pl.s1[i];
+    }
+    return pl.npass;
+}
+
 int ntt_butterflies(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse) {
     if (log_n > 30) return PLONK_HIP_ERR_INVALID_ARG;
     if (batch == 0 || log_n == 0) return PLONK_HIP_OK;

@@ -41,6 +41,7 @@ int interpolate_dev(plonk_hip_ctx *ctx, const Fr *d_x, const Fr *d_y, size_t n, 
 // inverse = bit-reversed in, natural out, scaled by 1/n
 int ntt_butterflies(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse);
 int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool inverse, const Fr *coset_shift);
+int ntt_plan_describe(uint32_t log_n, bool natural, int max_passes, uint32_t *s0, uint32_t *s1);
 // the same transform over Omega of size n = 2^k or 3 * 2^k
 int ntt_mixed_dev(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, bool inverse);
 int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch, int *d_divisible);

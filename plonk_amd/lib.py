@@ -68,6 +68,11 @@ SIGNATURES = {
     "plonk_hip_g1_decompress": (
         ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, c_u64p, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_hip_g1_compress": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_char_p]),
+    "plonk_hip_msm_plan_for": (
+        ctypes.c_int, [ctypes.c_size_t, ctypes.c_int, c_intp, c_intp, ctypes.POINTER(ctypes.c_size_t)]),
+    "plonk_hip_ntt_plan": (
+        ctypes.c_int, [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32),
+                       ctypes.POINTER(ctypes.c_uint32)]),
     "plonk_hip_bench_op_rate": (ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_gather_rate": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_fr_ntt_mixed": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),
