@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: G1 MSM throughput (Mpts/s) of one KZG commitment.
 
-Workload (BASELINE.json config 4): one 2^24-point BLS12-381 G1 MSM against a synthetic
+Workload: one 2^24-point BLS12-381 G1 MSM against a synthetic
 powers-of-tau SRS, sharded by point range over the N GPUs of one node.  Rank g keeps SRS points
 [g*n/N, (g+1)*n/N) resident (window tables built once, outside the timed region) and the
 matching coefficient slice resident in HBM; a step is one full commitment:

@@ -163,7 +163,7 @@ def test_open_matches_reference_definition(backend):
 
 
 def test_commit_2_16_points(backend):
-    # BASELINE config "single KZG commit: 2^16-point G1 MSM against a synthetic SRS"
+    # a single KZG commit: 2^16-point G1 MSM against a synthetic SRS
     rnd = random.Random(5)
     n = 1 << 16
     tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
@@ -200,7 +200,7 @@ def test_commit_2_20_points_known_answer(backend):
 
 
 def test_commit_2_24_points_known_answer(backend):
-    # BASELINE config "2^24-point G1 MSM": size-independent known answer commit == [f(tau)]G
+    # the 2^24-point G1 MSM of the benchmark: size-independent known answer commit == [f(tau)]G
     n = 1 << 24
     tau = c.fr_to_mont([0x1234567 + (1 << 200)])[0]
     backend.kzg_setup(tau, n - 1, want_points=False)
