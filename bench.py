@@ -102,6 +102,12 @@ def time_ntt(be, log_n, batch, reps):
         be.fr_ntt_dev(d, log_n, batch, False)
     be.sync()
     ntt_ms = (time.perf_counter() - t0) / reps * 1e3
+    # one transform on its own (latency rather than throughput)
+    t0 = time.perf_counter()
+    for _ in range(4 * reps):
+        be.fr_ntt_dev(d, log_n, 1, False)
+    be.sync()
+    single_ms = (time.perf_counter() - t0) / (4 * reps) * 1e3
     be.free(d)
     # quotient: batch polynomials of 2n coefficients -> n coefficients each
     f = synthetic_scalars(2 * n * batch, 8)
@@ -114,7 +120,29 @@ def time_ntt(be, log_n, batch, reps):
     be.sync()
     q_ms = (time.perf_counter() - t0) / reps * 1e3
     be.free(d)
-    return ntt_ms, q_ms
+    return ntt_ms, single_ms, q_ms
+
+
+def time_small_msm(log_n, reps):
+    """The second MSM size of the headline metric on its own context: scalars resident, Mpts/s."""
+    import plonk_amd
+
+    be = plonk_amd.Backend(device=0)
+    n = 1 << log_n
+    be.kzg_setup(np.array([3, 1, 4, 1], dtype=np.uint64), n - 1, want_points=False)
+    d_sc = be.to_device(synthetic_scalars(n, 2020))
+    d_out = be.malloc(144)
+    be.kzg_commit_dev(d_sc, n, d_out)
+    be.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        be.kzg_commit_dev(d_sc, n, d_out)
+    be.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    be.free(d_sc)
+    be.free(d_out)
+    be.close()
+    return ms
 
 
 def main():
@@ -260,8 +288,12 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             rec["cpu_baseline"] = cpu_baseline(be, n_local, args.cpu_sample_log, threads)
         if world == 1 and not args.no_extras:
-            ntt_ms, q_ms = time_ntt(be, 20, 16, 3)
+            ntt_ms, single_ms, q_ms = time_ntt(be, 20, 16, 3)
+            msm20_ms = time_small_msm(20, 10)
             rec["extras"] = {
+                "g1_msm_2^20_ms": round(msm20_ms, 3),
+                "g1_msm_2^20_mpts_per_s": round((1 << 20) / msm20_ms / 1e3, 1),
+                "fr_ntt_2^20_single_ms": round(single_ms, 4),
                 "fr_ntt_2^20_ms": round(ntt_ms / 16, 4),
                 "fr_ntt_2^20_batch16_ms": round(ntt_ms, 3),
                 "coset_quotient_16x2^20_ms": round(q_ms, 3),
