@@ -174,6 +174,30 @@ PLONK_HD bool xyzz28_madd_lazy(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2, bo
     return true;
 }
 
+// Lazy full addition for the tree sums behind the accumulation: out = a + b for two points in the
+// lazy form above (neither the identity; x < 5.1 q, y < 3.1 q, zz, zzz < 1.1 q; the result obeys the
+// same bounds, so sums of sums need no canonicalisation in between).  add-2008-s with 13
+// reductions for its 14 products.  Returns false, with out untouched, when the points are equal or
+// opposite: the caller resolves that on canonical values.
+PLONK_HD bool xyzz28_add_lazy(G1Xyzz28 &out, const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    Fq28 U1 = q28_mul_lazy(a.x, b.zz);                                    // < 1.01 q
+    Fq28 P = q28_sub_lazy<2>(q28_mul_lazy(b.x, a.zz), U1);                // U2 - U1     < 3.1 q
+    Fq28 S1 = q28_mul_lazy(a.y, b.zzz);
+    Fq28 R = q28_sub_lazy<2>(q28_mul_lazy(b.y, a.zzz), S1);               // S2 - S1     < 3.1 q
+    Fq28 PP = q28_mul_lazy(P, P);                                         //             < 1.01 q
+    if (q28_is_zero_mod_q(PP)) return false;
+    Fq28 PPP = q28_mul_lazy(P, PP);
+    Fq28 Q = q28_mul_lazy(U1, PP);
+    G1Xyzz28 r;
+    r.x = q28_sub2_lazy<4>(q28_mul_lazy(R, R), PPP, Q);                   // R^2 - PPP - 2Q  < 5.1 q
+    Fq28 negS1 = q28_sub_lazy<2>(q28_zero(), S1);                         // 2q - S1     <= 2 q
+    r.y = q28_mul2_lazy(R, q28_sub_lazy<6>(Q, r.x), negS1, PPP);          // R (Q - X3) - S1 PPP  < 1.1 q
+    r.zz = q28_mul_lazy(q28_mul_lazy(a.zz, b.zz), PP);
+    r.zzz = q28_mul_lazy(q28_mul_lazy(a.zzz, b.zzz), PPP);
+    out = r;
+    return true;
+}
+
 // Canonical representative of a lazily accumulated point.
 PLONK_HD G1Xyzz28 xyzz28_canon(const G1Xyzz28 &p) {
     if (xyzz28_is_identity(p)) return xyzz28_identity();

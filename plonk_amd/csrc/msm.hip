@@ -270,13 +270,29 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
 // ------------------------------------------------------------------------------------------
 // 5. fix-up: buckets cut by segment borders
 // ------------------------------------------------------------------------------------------
-// Full XYZZ addition with the (rare) equal-operands case out of line: one inlined copy per
-// kernel keeps the serial tails short without blowing up the code object.
-__device__ __forceinline__ G1Xyzz28 add_inline(const G1Xyzz28 &a, const G1Xyzz28 &b) {
+// Full XYZZ additions with the (rare) equal-or-opposite-operands case out of line: one inlined
+// copy per kernel keeps the serial tails short without blowing up the code object.
+// Canonical operands and result (the final Horner chain, which also doubles):
+__device__ __forceinline__ G1Xyzz28 add_canonical_inline(const G1Xyzz28 &a, const G1Xyzz28 &b) {
     G1Xyzz28 r;
     if (!xyzz28_add_nodbl(r, a, b)) {
         G1Xyzz28 t = a;  // a private copy: the caller's value keeps its registers
         r = dbl_cold(&t);
+    }
+    return r;
+}
+// Operands and result in the lazy form the accumulation leaves behind: the tree sums never
+// canonicalise in between.
+__device__ __noinline__ G1Xyzz28 add_slow_cold(const G1Xyzz28 *a, const G1Xyzz28 *b) {
+    return xyzz28_add(xyzz28_canon(*a), xyzz28_canon(*b));
+}
+__device__ __forceinline__ G1Xyzz28 add_inline(const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    if (xyzz28_is_identity(a)) return b;
+    if (xyzz28_is_identity(b)) return a;
+    G1Xyzz28 r;
+    if (!xyzz28_add_lazy(r, a, b)) {
+        G1Xyzz28 ta = a, tb = b;  // private copies: the caller's values keep their registers
+        r = add_slow_cold(&ta, &tb);
     }
     return r;
 }
@@ -319,10 +335,10 @@ __device__ __forceinline__ G1Xyzz28 shfl_point(const G1Xyzz28 &v, int src) {
 // of one sum go through a single inlined addition (selected operands, one loop).
 static constexpr int kTreeBlock = 256;  // largest block of the tree kernels
 
-// Sum of `cnt` points fetched through `at(j)` by one block of 64, 128 or 256 lanes; valid in
-// lane 0.  LAZY_IN: the fetched points come straight from k_accumulate and are canonicalised
-// first.  Wide blocks give the smallest depth, narrow ones the least idle work in the tree levels.
-template <bool LAZY_IN, class At>
+// Sum of `cnt` points (lazy form in, lazy form out) fetched through `at(j)` by one block of 64, 128
+// or 256 lanes; valid in lane 0.  Wide blocks give the smallest depth, narrow ones the least idle
+// work in the tree levels.
+template <class At>
 __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at) {
     const uint32_t t = threadIdx.x, lane = t & 63, width = blockDim.x;
     const uint32_t waves = width >> 6;                         // 1, 2 or 4
@@ -334,10 +350,7 @@ __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at)
         G1Xyzz28 o = xyzz28_identity();
         if (step < strided) {
             uint32_t j = step * width + t;
-            if (j < cnt) {
-                o = *at(j);
-                if (LAZY_IN) o = xyzz28_canon(o);
-            }
+            if (j < cnt) o = *at(j);
         } else if (step < strided + 6) {
             const int off = 32 >> (step - strided);
             o = shfl_down_point(acc, off, 64);
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict
             uint32_t lo = start[b], hi = start[b + 1];
             uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
             G1Xyzz28 acc =
-                block_sum<true>(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
+                block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
             if (threadIdx.x == 0) buckets[b] = acc;
         }
         return;
@@ -408,19 +421,17 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict
         }
     }
     const bool queued = cnt > per_lane * G;
+    const bool whole = cnt == 1;  // stored whole by k_accumulate: nothing to add
     G1Xyzz28 acc = xyzz28_identity();
     // strided terms: as many rounds as the longest bucket of this wave needs
-    const uint32_t need = queued ? 0u : (cnt + G - 1) >> g_log;
+    const uint32_t need = (queued || whole) ? 0u : (cnt + G - 1) >> g_log;
     uint32_t step = 0;
     int off = (int)(G >> 1);
     for (;;) {
         G1Xyzz28 o = xyzz28_identity();
         if (__any(step < need)) {  // the same answer in every lane of the wave
             const uint32_t j = step * G + r;
-            if (!queued && j < cnt) {
-                // a bucket inside one segment was stored whole; otherwise partial j of its run
-                o = xyzz28_canon(cnt == 1 ? buckets[b] : *partial_of(part, s0, j, lo, seg_len));
-            }
+            if (!queued && !whole && j < cnt) o = *partial_of(part, s0, j, lo, seg_len);
             step++;
         } else {
             if (off == 0) break;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict
         }
         acc = add_inline(acc, o);
     }
-    if (valid && r == 0 && !queued) buckets[b] = acc;
+    if (valid && r == 0 && !queued && !whole) buckets[b] = acc;  // identity for an empty bucket
 }
 
 // ------------------------------------------------------------------------------------------
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(const G1Xyzz28 *__r
     const bool row = i < H;
     const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
     const size_t stride = row ? 1 : L;
-    G1Xyzz28 acc = block_sum<false>(row ? L : H, sh, [&](uint32_t j) { return base + (size_t)j * stride; });
+    G1Xyzz28 acc = block_sum(row ? L : H, sh, [&](uint32_t j) { return base + (size_t)j * stride; });
     if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
 }
 
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restr
     const uint32_t nbits = low ? lbits : hbits;
     const uint32_t bit = all ? 31u : (low ? i : i - lbits);
     // j runs over the indices with `bit` removed; put a one back in at that position
-    G1Xyzz28 acc = block_sum<false>(all ? 1u << nbits : 1u << (nbits - 1), sh, [&](uint32_t j) {
+    G1Xyzz28 acc = block_sum(all ? 1u << nbits : 1u << (nbits - 1), sh, [&](uint32_t j) {
         return A + (all ? j : ((((j >> bit) << 1) | 1u) << bit | (j & ((1u << bit) - 1))));
     });
     if (threadIdx.x == 0) T[i] = acc;
@@ -476,7 +487,8 @@ __global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restr
 __global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t nbits, G1Jac *__restrict__ out) {
     const uint32_t d = threadIdx.x;
     const uint32_t ndig = (nbits + 2) / 3;
-    auto term = [&](uint32_t bit) { return (d < ndig && bit < nbits) ? T[bit] : xyzz28_identity(); };
+    // the per-bit sums arrive in the lazy form; this chain (it doubles) works on canonical values
+    auto term = [&](uint32_t bit) { return (d < ndig && bit < nbits) ? xyzz28_canon(T[bit]) : xyzz28_identity(); };
     // program: (double | add operand) steps through one inlined doubling and one inlined addition
     G1Xyzz28 acc = term(3 * d + 2);
     G1Xyzz28 own = xyzz28_identity();
@@ -501,13 +513,13 @@ __global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, u
                 acc = shfl_point(own, 0);
             }
             dbl = false;
-            o = T[nbits];  // T_all
+            o = xyzz28_canon(T[nbits]);  // T_all
         }
         if (dbl) {
             G1Xyzz28 t = acc;
             acc = dbl_cold(&t);
         } else {
-            acc = add_inline(acc, o);
+            acc = add_canonical_inline(acc, o);
         }
     }
     if (d == 0) *out = xyzz_to_jac(xyzz28_to(acc));

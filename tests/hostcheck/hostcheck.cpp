@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../plonk_amd/csrc/g1.cuh"
 #include "../../plonk_amd/csrc/field29.cuh"
@@ -164,6 +165,39 @@ extern "C" void hc_xyzz28_fold_lazy(const uint32_t *aff, const int *negate, size
         }
     }
     G1Xyzz r = xyzz28_to(xyzz28_canon(acc));
+    memcpy(out_xyzz, &r, sizeof(r));
+}
+
+// The tree sums behind the accumulation: every point enters as a lazily accumulated pair
+// (p + p' by the lazy mixed addition), the partial sums are joined by lazy full additions in a
+// binary tree, and only the end result is canonicalised (mirrors k_fixup / k_row_col_sums).
+static G1Xyzz28 lazy_sum(G1Xyzz28 a, G1Xyzz28 b) {
+    if (xyzz28_is_identity(a)) return b;
+    if (xyzz28_is_identity(b)) return a;
+    G1Xyzz28 r;
+    if (!xyzz28_add_lazy(r, a, b)) r = xyzz28_add(xyzz28_canon(a), xyzz28_canon(b));
+    return r;
+}
+extern "C" void hc_xyzz28_tree_lazy(const uint32_t *aff, const int *negate, size_t n, uint32_t *out_xyzz) {
+    std::vector<G1Xyzz28> level;
+    for (size_t i = 0; i < n; i++) {
+        G1Affine28 p = affine28_from(lda(aff + 24 * i));
+        G1Xyzz28 leaf = xyzz28_identity();
+        if (!affine28_is_identity(p)) {
+            leaf.x = p.x;
+            leaf.y = negate[i] ? q28_neg(p.y) : p.y;
+            leaf.zz = q28_one();
+            leaf.zzz = q28_one();
+        }
+        level.push_back(leaf);
+    }
+    while (level.size() > 1) {
+        std::vector<G1Xyzz28> next;
+        for (size_t i = 0; i + 1 < level.size(); i += 2) next.push_back(lazy_sum(level[i], level[i + 1]));
+        if (level.size() & 1) next.push_back(level.back());
+        level.swap(next);
+    }
+    G1Xyzz r = xyzz28_to(xyzz28_canon(level.empty() ? xyzz28_identity() : level[0]));
     memcpy(out_xyzz, &r, sizeof(r));
 }
 

@@ -181,7 +181,8 @@ def test_28_bit_bucket_accumulation(hc):
     def fold(seq):
         strict = fold_with(hc.hc_xyzz28_fold, seq)
         lazy = fold_with(hc.hc_xyzz28_fold_lazy, seq)  # the accumulation loop's lazy arithmetic
-        assert o.g1_to_affine(strict) == o.g1_to_affine(lazy)
+        tree = fold_with(hc.hc_xyzz28_tree_lazy, seq)  # the tree sums' lazy full additions
+        assert o.g1_to_affine(strict) == o.g1_to_affine(lazy) == o.g1_to_affine(tree)
         return lazy
 
     rt = np.empty(12, dtype=np.uint64)
