@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=24, help="log2 of the MSM size (whole job)")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--exchange", choices=["points", "buckets"], default="points",
+                    help="what the ranks exchange: reduced partial points (144 B each) or bucket partials")
     ap.add_argument("--cpu-sample-log", type=int, default=19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -208,8 +210,17 @@ def main():
 
     from plonk_amd import sharding
 
+    use_buckets = args.exchange == "buckets" and world > 1
+    if use_buckets:
+        nbuckets, each = be.msm_bucket_layout()
+        send = torch.empty(nbuckets * each, dtype=torch.uint8, device=dev)
+        recv = torch.empty(nbuckets * each, dtype=torch.uint8, device=dev)
+
     def step(record):
-        sharding.commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt)
+        if use_buckets:
+            sharding.commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathered, total_pt)
+        else:
+            sharding.commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt)
         if record:
             phases.append(be.msm_phase_ms())  # waits for this step's MSM events
 
@@ -263,7 +274,9 @@ def main():
                 "window_bits": plan["window_bits"],
                 "windows": plan["windows"],
                 "buckets": plan["buckets"],
-                "parallelism": "point-range x%d, all_gather of %d-byte partials" % (world, 144),
+                "parallelism": ("point-range x%d, all_to_all of bucket partials (%d B per rank)"
+                                % (world, nbuckets * each)) if use_buckets else
+                               "point-range x%d, all_gather of %d-byte partials" % (world, 144),
                 "srs_setup_s": round(t_setup, 2),
             },
             "roofline": {

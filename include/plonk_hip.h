@@ -132,6 +132,24 @@ int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs
  * partial commitments after they have been gathered (the `+` of kzg.rs:57 across shards). */
 int plonk_hip_g1_sum_dev(plonk_hip_ctx *ctx, const void *d_pts, size_t n, void *d_out);
 
+/* Exchange of bucket partials between GPUs (the other way to split the sum of kzg.rs:53-58 over
+ * point ranges): every rank stops its local commitment after the bucket sums, the ranks exchange
+ * slices of their bucket arrays (all-to-all of opaque bytes), and each rank adds up and reduces
+ * one slice, which spreads the serial bucket reduction over the GPUs.
+ *   _bucket_layout:  number of buckets of the installed SRS's window plan and bytes per bucket
+ *                    (equal on ranks that hold equally many points).
+ *   _buckets_dev:    the commitment of d_coeffs (n x 4, device) up to the bucket sums, written to
+ *                    d_buckets (nbuckets x bytes_per_bucket of device memory).
+ *   _reduce_bucket_slice_dev: d_parts = nparts arrays of `count` buckets each, all for buckets
+ *                    [first, first + count) (count a power of two >= 4, first a multiple of count);
+ *                    d_out (18 words, device) = this slice's share of the commitment.  The shares
+ *                    of all slices add up (plonk_hip_g1_sum_dev) to what plonk_hip_kzg_commit_dev
+ *                    returns for the concatenated input. */
+int plonk_hip_msm_bucket_layout(plonk_hip_ctx *ctx, size_t *nbuckets, size_t *bytes_per_bucket);
+int plonk_hip_msm_buckets_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_buckets);
+int plonk_hip_msm_reduce_bucket_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first,
+                                          size_t count, void *d_out);
+
 /* `kzg_evaluate(gp, f, u)` (kzg.rs:63-88): v = f(u); q = (f - v) / (X - u);
  * proof = sum_i q_i * tau_powers_g1[i].  n = coeffs.len().
  * n < 2 -> PLONK_HIP_ERR_EMPTY_POLY (empty quotient); n - 1 > SRS size -> SRS_TOO_SHORT. */

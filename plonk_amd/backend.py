@@ -213,6 +213,21 @@ class Backend:
     def g1_sum_dev(self, d_pts, n, d_out):
         self._check(self._lib.plonk_hip_g1_sum_dev(self._ctx, d_pts, n, d_out))
 
+    def msm_bucket_layout(self):
+        """(number of buckets, bytes per bucket) of the installed SRS's window plan."""
+        nb, each = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self._lib.plonk_hip_msm_bucket_layout(self._ctx, ctypes.byref(nb), ctypes.byref(each)))
+        return nb.value, each.value
+
+    def msm_buckets_dev(self, d_coeffs, n, d_buckets):
+        """Commitment of d_coeffs up to the bucket sums (opaque bytes at d_buckets)."""
+        self._check(self._lib.plonk_hip_msm_buckets_dev(self._ctx, d_coeffs, n, d_buckets))
+
+    def msm_reduce_bucket_slice_dev(self, d_parts, nparts, first, count, d_out):
+        """Share of the commitment carried by buckets [first, first + count), summed over nparts
+        bucket partials."""
+        self._check(self._lib.plonk_hip_msm_reduce_bucket_slice_dev(self._ctx, d_parts, nparts, first, count, d_out))
+
     # ------------------------------------------------------------------ commit / open
     def kzg_commit(self, coeffs):
         """`kzg_commit(gp, f)` (kzg.rs:48-60) -> (18,) Jacobian limbs."""

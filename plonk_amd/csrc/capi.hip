@@ -225,6 +225,28 @@ int plonk_hip_g1_sum_dev(plonk_hip_ctx *ctx, const void *d_pts, size_t n, void *
     return g1_sum_dev(ctx, (const G1Jac *)d_pts, n, (G1Jac *)d_out);
 }
 
+int plonk_hip_msm_bucket_layout(plonk_hip_ctx *ctx, size_t *nbuckets, size_t *bytes_per_bucket) {
+    PLONK_ENTER(ctx);
+    if (!nbuckets || !bytes_per_bucket) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    *nbuckets = ctx->plan.nbuckets;
+    *bytes_per_bucket = msm_bucket_bytes();
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_msm_buckets_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_buckets) {
+    PLONK_ENTER(ctx);
+    if (!d_coeffs || !d_buckets) return PLONK_HIP_ERR_INVALID_ARG;
+    return msm_run_dev(ctx, (const Fr *)d_coeffs, n, nullptr, d_buckets);
+}
+
+int plonk_hip_msm_reduce_bucket_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first,
+                                          size_t count, void *d_out) {
+    PLONK_ENTER(ctx);
+    if (!d_parts || !d_out) return PLONK_HIP_ERR_INVALID_ARG;
+    return msm_reduce_slice_dev(ctx, d_parts, nparts, first, count, (G1Jac *)d_out);
+}
+
 // ---------------------------------------------------------------------------- commit / open
 int plonk_hip_kzg_commit_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, void *d_out) {
     PLONK_ENTER(ctx);

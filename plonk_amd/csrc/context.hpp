@@ -87,7 +87,10 @@ void buf_release(DevBuf &b);
 // msm.hip
 MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
 // d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
-int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out);
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out = nullptr);
+int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first, size_t count,
+                         G1Jac *d_out);
+size_t msm_bucket_bytes();
 // d_out = sum of n Jacobian points in device memory (the gathered per-GPU partial results)
 int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out);
 

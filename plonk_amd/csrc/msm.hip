@@ -484,11 +484,19 @@ __global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restr
 
 // One wave.  Lane d forms the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2); lane 0 then runs
 // S = (..(U_top * 8 + U_(top-1)) * 8 + ..) + U_0 + T_all.  Jacobian result.
-__global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t nbits, G1Jac *__restrict__ out) {
+// For a slice [first, first + 2^sbits) of a larger bucket array (first a multiple of 2^sbits, T the
+// bit sums of the slice, T[sbits] its total) the bits of `first` stand for the whole slice:
+// T_i = T_all for a set bit i >= sbits of first, O for a clear one.
+__global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t sbits, uint32_t nbits,
+                                               uint32_t first, G1Jac *__restrict__ out) {
     const uint32_t d = threadIdx.x;
     const uint32_t ndig = (nbits + 2) / 3;
     // the per-bit sums arrive in the lazy form; this chain (it doubles) works on canonical values
-    auto term = [&](uint32_t bit) { return (d < ndig && bit < nbits) ? xyzz28_canon(T[bit]) : xyzz28_identity(); };
+    auto term = [&](uint32_t bit) {
+        if (d >= ndig || bit >= nbits) return xyzz28_identity();
+        if (bit < sbits) return xyzz28_canon(T[bit]);
+        return ((first >> bit) & 1u) ? xyzz28_canon(T[sbits]) : xyzz28_identity();
+    };
     // program: (double | add operand) steps through one inlined doubling and one inlined addition
     G1Xyzz28 acc = term(3 * d + 2);
     G1Xyzz28 own = xyzz28_identity();
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, u
                 acc = shfl_point(own, 0);
             }
             dbl = false;
-            o = xyzz28_canon(T[nbits]);  // T_all
+            o = xyzz28_canon(T[sbits]);  // T_all
         }
         if (dbl) {
             G1Xyzz28 t = acc;
@@ -523,6 +531,18 @@ __global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, u
         }
     }
     if (d == 0) *out = xyzz_to_jac(xyzz28_to(acc));
+}
+
+// B[b] = sum over p of parts[p * count + b]: the bucket partials of `nparts` GPUs for one slice of
+// the bucket array, one lane per bucket.
+__global__ __launch_bounds__(128) void k_sum_parts(const G1Xyzz28 *__restrict__ parts, uint32_t nparts, uint32_t count,
+                                                   G1Xyzz28 *__restrict__ B) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    G1Xyzz28 acc = parts[b];
+#pragma unroll 1
+    for (uint32_t p = 1; p < nparts; p++) acc = add_inline(acc, parts[(size_t)p * count + b]);
+    B[b] = acc;
 }
 
 // out = sum of n Jacobian points (n is the number of GPUs: a handful)
@@ -590,7 +610,54 @@ int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out) {
     return PLONK_HIP_OK;
 }
 
-int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out) {
+size_t msm_bucket_bytes() { return sizeof(G1Xyzz28); }
+
+// S = sum_b (first + b + 1) B[b] over the 2^sbits buckets at B, as a Jacobian point at d_out;
+// `first` is a multiple of 2^sbits below 2^nbits (0 and sbits == nbits for a whole bucket array).
+static int reduce_buckets(plonk_hip_ctx *ctx, const G1Xyzz28 *B, uint32_t sbits, uint32_t nbits, uint32_t first,
+                          G1Jac *d_out) {
+    hipStream_t st = ctx->stream;
+    const uint32_t lbits = (sbits + 1) / 2, hbits = sbits - lbits;
+    const uint32_t L = 1u << lbits, H = 1u << hbits;
+    PLONK_TRY(buf_reserve(ctx, ctx->red_a, ((size_t)H + L + sbits + 1) * sizeof(G1Xyzz28)));
+    G1Xyzz28 *R = (G1Xyzz28 *)ctx->red_a.ptr, *C = R + H, *T = C + L;
+    // one sum per block: wide blocks (small depth) while they are few, one wave per sum once
+    // there is a sum for every SIMD (the tree levels of a wide block are mostly idle lanes)
+    const uint32_t sums = H + L;
+    const uint32_t width = sums >= 1024 ? 64u : (sums >= 512 ? 128u : 256u);
+    hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, B, H, L, R, C);
+    hipLaunchKernelGGL(k_bit_sums, dim3(sbits + 1), dim3(kTreeBlock), 0, st, R, hbits, C, lbits, T);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, T, sbits, nbits, first, d_out);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+// Multi-GPU exchange of bucket partials: rank g receives, from every rank, that rank's partial
+// sums of the buckets [first, first + count) and finishes that slice.  parts: nparts arrays of
+// count buckets each (the layout msm_run_dev leaves in d_buckets_out), count a power of two >= 4,
+// first a multiple of count.
+int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first, size_t count,
+                         G1Jac *d_out) {
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    const uint32_t nb = ctx->plan.nbuckets;
+    if (nparts == 0 || nparts > 1024 || count < 4 || (count & (count - 1)) || count > nb || first % count ||
+        first + count > nb)
+        return PLONK_HIP_ERR_INVALID_ARG;
+    uint32_t sbits = 0;
+    while (((size_t)1 << sbits) < count) sbits++;
+    const G1Xyzz28 *B = (const G1Xyzz28 *)d_parts;
+    if (nparts > 1) {
+        PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
+        hipLaunchKernelGGL(k_sum_parts, dim3(cdiv(count, 128)), dim3(128), 0, ctx->stream, B, (uint32_t)nparts,
+                           (uint32_t)count, (G1Xyzz28 *)ctx->buckets.ptr);
+        B = (const G1Xyzz28 *)ctx->buckets.ptr;
+    }
+    return reduce_buckets(ctx, B, sbits, (uint32_t)ctx->plan.c - 1, (uint32_t)first, d_out);
+}
+
+// d_out: the MSM as a Jacobian point.  With d_buckets_out set (nbuckets x sizeof(G1Xyzz28) bytes of
+// device memory) the pipeline stops after the fix-up and leaves the bucket sums there instead.
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out) {
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
     if (n > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
@@ -618,14 +685,14 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
     PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
-    PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
+    if (!d_buckets_out) PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
     PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz28)));
     PLONK_TRY(buf_reserve(ctx, ctx->big_list, ((size_t)nb + 1) * 4));
 
     uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
     uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
     uint32_t *start = (uint32_t *)ctx->bucket_start.ptr;
-    G1Xyzz28 *buckets = (G1Xyzz28 *)ctx->buckets.ptr;
+    G1Xyzz28 *buckets = d_buckets_out ? (G1Xyzz28 *)d_buckets_out : (G1Xyzz28 *)ctx->buckets.ptr;
     G1Xyzz28 *part = (G1Xyzz28 *)ctx->seg_part.ptr;
     const G1Affine28 *table = (const G1Affine28 *)ctx->table.ptr;
     uint32_t *big_count = (uint32_t *)ctx->big_list.ptr, *big_list = big_count + 1;
@@ -667,20 +734,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out)
     hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, st, start, nb, seg_len, part,
                        buckets, g_log, per_lane, group_blocks, big_count, big_list);
     record(ctx, PH_REDUCE);
-    {
-        const uint32_t nbits = (uint32_t)pl.c - 1;
-        const uint32_t lbits = (nbits + 1) / 2, hbits = nbits - lbits;
-        const uint32_t L = 1u << lbits, H = 1u << hbits;
-        PLONK_TRY(buf_reserve(ctx, ctx->red_a, ((size_t)H + L + nbits + 1) * sizeof(G1Xyzz28)));
-        G1Xyzz28 *R = (G1Xyzz28 *)ctx->red_a.ptr, *C = R + H, *T = C + L;
-        // one sum per block: wide blocks (small depth) while they are few, one wave per sum once
-        // there is a sum for every SIMD (the tree levels of a wide block are mostly idle lanes)
-        const uint32_t sums = H + L;
-        const uint32_t width = sums >= 1024 ? 64u : (sums >= 512 ? 128u : 256u);
-        hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, buckets, H, L, R, C);
-        hipLaunchKernelGGL(k_bit_sums, dim3(nbits + 1), dim3(kTreeBlock), 0, st, R, hbits, C, lbits, T);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, T, nbits, d_out);
-    }
+    if (!d_buckets_out) PLONK_TRY(reduce_buckets(ctx, buckets, (uint32_t)pl.c - 1, (uint32_t)pl.c - 1, 0, d_out));
     record(ctx, PH_COUNT);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;

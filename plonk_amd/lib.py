@@ -33,6 +33,10 @@ SIGNATURES = {
     "plonk_hip_kzg_setup": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_kzg_setup_range": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_size_t, c_u64p]),
     "plonk_hip_g1_sum_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_hip_msm_bucket_layout": (ctypes.c_int, [c_ctx, c_sizep, c_sizep]),
+    "plonk_hip_msm_buckets_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_hip_msm_reduce_bucket_slice_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_kzg_commit": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_kzg_commit_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_kzg_commit_batch": (

@@ -5,7 +5,10 @@
 Rank g keeps SRS points [first_g, first_g + count_g) and the matching coefficients resident and
 runs the whole local MSM; the only exchange is an all_gather of the 144-byte partial points
 (raw bytes -- point addition is not a reduce-op, so never all_reduce), after which rank 0 adds
-them.  One process per GPU; `torch.distributed` supplies the collective (backend "nccl" is RCCL
+them (`commit_sharded`).  `commit_sharded_buckets` exchanges bucket partials instead: every rank
+stops after its bucket sums, an all_to_all hands rank g everybody's partials of bucket slice g,
+and rank g adds them up and reduces that slice, so the serial bucket reduction is spread over
+the ranks at the price of moving the bucket arrays.  One process per GPU; `torch.distributed` supplies the collective (backend "nccl" is RCCL
 over xGMI on ROCm; "gloo" on CPU tensors for tests)."""
 import torch
 import torch.distributed as dist
@@ -48,5 +51,52 @@ def commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt, group=N
     gather_partials(local_pt, gathered, group)
     torch.cuda.current_stream().synchronize()
     if dist.get_rank(group) == 0:
+        be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
+    return total_pt
+
+
+def bucket_slice(nbuckets, world, rank):
+    """Bucket range of rank in the bucket-partial exchange: (first, count).  The slices must be
+    equal powers of two of at least 4 buckets."""
+    if world & (world - 1) or nbuckets % world or nbuckets // world < 4:
+        raise ValueError("bucket exchange needs a power-of-two number of ranks and >= 4 buckets per rank")
+    count = nbuckets // world
+    return rank * count, count
+
+
+def exchange_bucket_slices(send, recv, group=None):
+    """send: uint8 tensor holding this rank's whole bucket array (world equal slices); recv: same
+    size, receives slice `rank` of every rank's array, ordered by source rank."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a box without RCCL peers: stage the arrays through the host
+        staged = torch.empty(send.numel(), dtype=send.dtype)
+        dist.all_to_all_single(staged, send.cpu(), group=group)
+        recv.copy_(staged)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+    return recv
+
+
+def commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathered, total_pt, group=None):
+    """One sharded commitment step with the bucket-partial exchange: local bucket sums (library
+    stream) -> all_to_all of bucket slices -> slice reduction -> all_gather of the slice shares
+    -> sum on rank 0 into total_pt.  send/recv: uint8 GPU tensors of nbuckets * bytes_per_bucket
+    (see Backend.msm_bucket_layout); every rank must hold equally many points."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        be.kzg_commit_dev(d_scalars, n_local, local_pt.data_ptr())
+        return local_pt
+    rank = dist.get_rank(group)
+    nbuckets, _ = be.msm_bucket_layout()
+    first, count = bucket_slice(nbuckets, world, rank)
+    be.msm_buckets_dev(d_scalars, n_local, send.data_ptr())
+    be.sync()  # the collectives run on torch's stream
+    exchange_bucket_slices(send, recv, group)
+    torch.cuda.current_stream().synchronize()
+    be.msm_reduce_bucket_slice_dev(recv.data_ptr(), world, first, count, local_pt.data_ptr())
+    be.sync()
+    gather_partials(local_pt, gathered, group)
+    torch.cuda.current_stream().synchronize()
+    if rank == 0:
         be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
     return total_pt

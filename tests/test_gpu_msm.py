@@ -224,6 +224,57 @@ def test_commit_2_24_points_known_answer(backend):
     backend.free(d_out)
 
 
+@pytest.mark.parametrize("log_n,ranks,window_bits", [(18, 4, 0), (14, 2, 9), (12, 8, 6)])
+def test_bucket_partial_exchange(backend, log_n, ranks, window_bits):
+    """The multi-GPU exchange of bucket partials, with the ranks played one after the other on this
+    GPU: every rank stops after its bucket sums, slice g of every rank's array goes to rank g, the
+    slice shares add up to the commitment."""
+    n = 1 << log_n
+    per = n // ranks
+    rnd = random.Random(40 + log_n)
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    sc = np.frombuffer(rnd.randbytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    sc[5] = 0
+    sc[per:per + 40] = sc[7]  # a crowded bucket on rank 1
+    backend.set_window_bits(window_bits)
+    arrays = []
+    for r in range(ranks):
+        backend.kzg_setup_range(tau, r * per, per)
+        nb, each = backend.msm_bucket_layout()
+        assert nb == backend.msm_plan()["buckets"]
+        d_sc = backend.to_device(sc[r * per:(r + 1) * per])
+        d_b = backend.malloc(nb * each)
+        backend.msm_buckets_dev(d_sc, per, d_b)
+        backend.sync()
+        arrays.append(backend.from_device(d_b, (nb, each), dtype=np.uint8))
+        backend.free(d_sc)
+        backend.free(d_b)
+    count = nb // ranks
+    d_shares = backend.malloc(ranks * 144)
+    for g in range(ranks):  # what rank g holds after the all_to_all
+        parts = np.stack([a[g * count:(g + 1) * count] for a in arrays])
+        d_parts = backend.to_device(parts)
+        backend.msm_reduce_bucket_slice_dev(d_parts, ranks, g * count, count, d_shares + g * 144)
+        backend.sync()
+        backend.free(d_parts)
+    d_out = backend.malloc(144)
+    backend.g1_sum_dev(d_shares, ranks, d_out)
+    backend.sync()
+    got = backend.from_device(d_out, (18,))
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+    # one part, whole array: the same as the single-GPU commitment of that rank's range
+    d_parts = backend.to_device(arrays[-1])
+    backend.msm_reduce_bucket_slice_dev(d_parts, 1, 0, nb, d_out)
+    backend.sync()
+    assert same_point(backend.from_device(d_out, (18,)), backend.kzg_commit(sc[(ranks - 1) * per:]))
+    with pytest.raises(plonk_amd.PlonkHipError):
+        backend.msm_reduce_bucket_slice_dev(d_parts, 1, count // 2, count, d_out)  # misaligned slice
+    for ptr in (d_parts, d_shares, d_out):
+        backend.free(ptr)
+    backend.set_window_bits(0)
+
+
 def test_commit_2_26_points_known_answer(backend):
     # the largest size whose 12 window tables (96 GiB) fit beside the work buffers in 288 GB
     n = 1 << 26

@@ -1,5 +1,6 @@
 """world_size-2 rehearsal of the multi-GPU commitment on CPU (gloo): range split, all_gather of
-the partial points, combination on rank 0.  The per-rank MSM itself is stood in by the oracle
+the partial points (or all_to_all of bucket partials and per-rank slice reduction), combination
+on rank 0.  The per-rank MSM itself is stood in by the oracle
 here (no GPU in this suite); on GPUs the same protocol runs with plonk_hip_kzg_commit_dev."""
 import os
 import random
@@ -60,3 +61,63 @@ def test_gathered_partials_sum_to_the_commitment(tmp_path, world, n):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, port, n, 77, str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+def _bucket_worker(rank, world, port, nbuckets, seed, out_path):
+    """Bucket-partial exchange with 144-byte Jacobian points standing in for the device's bucket
+    format: rank r holds a full array of bucket partials; after the all_to_all it reduces slice r."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gen = c.g1_generator()
+
+    def partials_of(r):
+        rnd = random.Random(seed + r)
+        ks = [rnd.randrange(o.R) if rnd.random() < 0.8 else 0 for _ in range(nbuckets)]  # some empty buckets
+        return ks, np.stack([c.g1_mul(gen, c.fr_to_mont([k])[0]) for k in ks])
+
+    _, mine = partials_of(rank)
+    send = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+    recv = torch.empty_like(send)
+    sharding.exchange_bucket_slices(send, recv)
+    first, count = sharding.bucket_slice(nbuckets, world, rank)
+    parts = recv.numpy().view(np.uint64).reshape(world, count, 18)
+    share = c.g1_identity()
+    for b in range(count):
+        bucket = c.g1_identity()
+        for src in range(world):
+            bucket = c.g1_add(bucket, parts[src, b])
+        share = c.g1_add(share, c.g1_mul(bucket, c.fr_to_mont([first + b + 1])[0]))
+    gathered = sharding.gather_partials(torch.from_numpy(share.view(np.int64).copy()))
+    if rank == 0:
+        total = c.g1_identity()
+        for r in range(world):
+            total = c.g1_add(total, gathered[r].numpy().view(np.uint64))
+        k = 0
+        for r in range(world):
+            ks, _ = partials_of(r)
+            k += sum((b + 1) * kb for b, kb in enumerate(ks))
+        want = c.g1_mul(gen, c.fr_to_mont([k % o.R])[0])
+        ok = c.g1_compress(total.reshape(1, 18)) == c.g1_compress(want.reshape(1, 18))
+        with open(out_path, "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbuckets", [(2, 16), (4, 16)])
+def test_bucket_partial_exchange_sums_to_the_commitment(tmp_path, world, nbuckets):
+    c.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "result.txt"
+    mp.spawn(_bucket_worker, args=(world, port, nbuckets, 91, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_bucket_slices_need_a_power_of_two_split():
+    assert sharding.bucket_slice(1 << 19, 8, 3) == (3 << 16, 1 << 16)
+    for nb, world in ((16, 3), (16, 8), (12, 4)):
+        with pytest.raises(ValueError):
+            sharding.bucket_slice(nb, world, 0)
