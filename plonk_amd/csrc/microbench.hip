@@ -320,6 +320,10 @@ __global__ __launch_bounds__(256) void k_op_rate(uint32_t *__restrict__ out, uin
                 if (OP == 7) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(*(uint32_t *)&r[j]) : "v"(b));
                 if (OP == 8) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[j]) : "v"(a), "v"(b) : "vcc");
                 if (OP == 9) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(*(uint32_t *)&r[j]) : "v"(a));
+                // the multiply-add again with every operation waiting for the one before it (10) or
+                // for the one two before it (11)
+                if (OP == 10) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[0]) : "v"(a), "v"(b) : "vcc");
+                if (OP == 11) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[j & 1]) : "v"(a), "v"(b) : "vcc");
             }
         }
     }
@@ -332,9 +336,12 @@ __global__ __launch_bounds__(256) void k_op_rate(uint32_t *__restrict__ out, uin
 // Wave-instructions per second per SIMD-equivalent are derived by the caller; this returns lane
 // operations per second for instruction `op`:
 // 0 v_lshrrev_b64, 1 v_lshl_add_u64, 2 v_alignbit_b32, 3 v_and_b32, 4 v_add3_u32, 5 v_mad_i64_i32,
-// 6 v_ashrrev_i64, 7 v_mul_lo_u32, 8 v_mad_u64_u32, 9 v_sub_u32.
+// 6 v_ashrrev_i64, 7 v_mul_lo_u32, 8 v_mad_u64_u32, 9 v_sub_u32, 10 / 11 v_mad_u64_u32 in one / two
+// dependent chains (0-9 run eight independent chains).  op + 100: one wave per SIMD instead of eight.
 int bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) {
-    const int blocks = 256 * 8, threads = 256, iters = 2048;
+    const bool lone = op >= 100;
+    if (lone) op -= 100;
+    const int blocks = lone ? 1024 : 256 * 8, threads = lone ? 64 : 256, iters = 2048;
     PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (size_t)blocks * threads * 4));
     uint32_t *out = (uint32_t *)ctx->scratch_c.ptr;
     hipEvent_t e0, e1;
@@ -347,6 +354,7 @@ int bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) {
         switch (op) {
             PLONK_OP_CASE(0) PLONK_OP_CASE(1) PLONK_OP_CASE(2) PLONK_OP_CASE(3) PLONK_OP_CASE(4)
             PLONK_OP_CASE(5) PLONK_OP_CASE(6) PLONK_OP_CASE(7) PLONK_OP_CASE(8) PLONK_OP_CASE(9)
+            PLONK_OP_CASE(10) PLONK_OP_CASE(11)
             default: (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return PLONK_HIP_ERR_INVALID_ARG;
         }
 #undef PLONK_OP_CASE

@@ -482,55 +482,43 @@ __global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restr
     if (threadIdx.x == 0) T[i] = acc;
 }
 
-// One wave.  Lane d forms the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2); lane 0 then runs
-// S = (..(U_top * 8 + U_(top-1)) * 8 + ..) + U_0 + T_all.  Jacobian result.
+// One wave.  Lane d < ndig forms the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2) and doubles
+// it 3d times; lane ndig holds T_all; a shuffle tree adds the ndig + 1 terms:
+//   S = sum_d 8^d U_d + T_all.
+// The doublings of the lanes run side by side, so the chain is 4 + 3 (ndig - 1) short steps and
+// log2(ndig + 1) additions instead of one addition per digit.  Jacobian result.
 // For a slice [first, first + 2^sbits) of a larger bucket array (first a multiple of 2^sbits, T the
 // bit sums of the slice, T[sbits] its total) the bits of `first` stand for the whole slice:
 // T_i = T_all for a set bit i >= sbits of first, O for a clear one.
 __global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t sbits, uint32_t nbits,
                                                uint32_t first, G1Jac *__restrict__ out) {
     const uint32_t d = threadIdx.x;
-    const uint32_t ndig = (nbits + 2) / 3;
-    // the per-bit sums arrive in the lazy form; this chain (it doubles) works on canonical values
+    const uint32_t ndig = (nbits + 2) / 3;  // at most 8: nbits <= 23
+    // the per-bit sums arrive in the lazy form; doublings work on canonical values
     auto term = [&](uint32_t bit) {
         if (d >= ndig || bit >= nbits) return xyzz28_identity();
         if (bit < sbits) return xyzz28_canon(T[bit]);
         return ((first >> bit) & 1u) ? xyzz28_canon(T[sbits]) : xyzz28_identity();
     };
-    // program: (double | add operand) steps through one inlined doubling and one inlined addition
     G1Xyzz28 acc = term(3 * d + 2);
-    G1Xyzz28 own = xyzz28_identity();
-    const uint32_t steps = 4 + 4 * (ndig - 1) + 1;
+    // U_d: (double, add T_(3d+1), double, add T_3d), then 3d doublings in the lanes that need them
+    const uint32_t steps = 4 + 3 * (ndig - 1);
     for (uint32_t step = 0; step < steps; step++) {
-        bool dbl;
-        G1Xyzz28 o = xyzz28_identity();
-        if (step < 4) {
-            dbl = (step & 1) == 0;
-            if (!dbl) o = term(3 * d + (step == 1 ? 1 : 0));
-        } else if (step < steps - 1) {
-            if (step == 4) {
-                own = acc;                       // U_d
-                acc = shfl_point(own, (int)ndig - 1);  // every lane follows lane 0's chain
-            }
-            const uint32_t q = step - 4;         // groups of (dbl, dbl, dbl, add U_dig)
-            dbl = (q & 3) != 3;
-            if (!dbl) o = shfl_point(own, (int)(ndig - 2 - (q >> 2)));
-        } else {
-            if (step == 4) {
-                own = acc;
-                acc = shfl_point(own, 0);
-            }
-            dbl = false;
-            o = xyzz28_canon(T[sbits]);  // T_all
-        }
+        const bool dbl = step >= 4 ? step - 4 < 3 * d && d < ndig : (step & 1) == 0;
         if (dbl) {
             G1Xyzz28 t = acc;
             acc = dbl_cold(&t);
-        } else {
-            acc = add_canonical_inline(acc, o);
+        } else if (step < 4) {
+            acc = add_canonical_inline(acc, term(3 * d + (step == 1 ? 1 : 0)));
         }
     }
-    if (d == 0) *out = xyzz_to_jac(xyzz28_to(acc));
+    if (d == ndig) acc = T[sbits];  // T_all (lazy form, like every operand of the tree below)
+    for (int off = 8; off > 0; off >>= 1) {
+        G1Xyzz28 o = shfl_down_point(acc, off, 64);
+        if ((int)d >= off || d + off > ndig) o = xyzz28_identity();
+        acc = add_inline(acc, o);
+    }
+    if (d == 0) *out = xyzz_to_jac(xyzz28_to(xyzz28_canon(acc)));
 }
 
 // B[b] = sum over p of parts[p * count + b]: the bucket partials of `nparts` GPUs for one slice of

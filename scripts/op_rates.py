@@ -14,3 +14,11 @@ for op, name in enumerate(names):
     # 1024 SIMDs x 64 lanes
     cyc = 1024 * 64 * ghz * 1e9 / r
     print("%-16s %8.2f Tlane-op/s  %.2f cycles per wave-instruction at %.2f GHz" % (name, r / 1e12, cyc, ghz), flush=True)
+
+# one wave per SIMD: does a lone wave reach the issue rate, and what does dependence cost?
+for op, name in ((108, "v_mad_u64_u32, 8 chains, lone wave"), (111, "v_mad_u64_u32, 2 chains, lone wave"),
+                 (110, "v_mad_u64_u32, 1 chain, lone wave"), (10, "v_mad_u64_u32, 1 chain, 8 waves"),
+                 (101, "v_lshl_add_u64, 8 chains, lone wave"), (103, "v_and_b32, 8 chains, lone wave")):
+    r = be.bench_op_rate(op)
+    cyc = 1024 * 64 * ghz * 1e9 / r
+    print("%-38s %8.2f Tlane-op/s  %.2f cycles per wave-instruction" % (name, r / 1e12, cyc), flush=True)
