@@ -24,6 +24,7 @@
 #include <cmath>
 
 #include "context.hpp"
+#include "coop28.cuh"
 #include "g1_28.cuh"
 #include "msm_core.cuh"
 
@@ -272,15 +273,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
 // ------------------------------------------------------------------------------------------
 // Full XYZZ additions with the (rare) equal-or-opposite-operands case out of line: one inlined
 // copy per kernel keeps the serial tails short without blowing up the code object.
-// Canonical operands and result (the final Horner chain, which also doubles):
-__device__ __forceinline__ G1Xyzz28 add_canonical_inline(const G1Xyzz28 &a, const G1Xyzz28 &b) {
-    G1Xyzz28 r;
-    if (!xyzz28_add_nodbl(r, a, b)) {
-        G1Xyzz28 t = a;  // a private copy: the caller's value keeps its registers
-        r = dbl_cold(&t);
-    }
-    return r;
-}
 // Operands and result in the lazy form the accumulation leaves behind: the tree sums never
 // canonicalise in between.
 __device__ __noinline__ G1Xyzz28 add_slow_cold(const G1Xyzz28 *a, const G1Xyzz28 *b) {
@@ -369,6 +361,137 @@ __device__ __forceinline__ G1Xyzz28 block_sum(uint32_t cnt, G1Xyzz28 *sh, At at)
     }
     __syncthreads();  // sh may be reused by the caller's next sum
     return acc;
+}
+
+// ---- sums by four cooperating waves ----------------------------------------------------------
+// Where only a few blocks are left to run (the per-bit sums, the final chain, the row and column
+// sums of a small bucket array) a block of four waves works on 64 slots at once with the staged
+// formulas of coop28.cuh: values live in LDS as [value][limb][slot] (conflict-free for a wave).
+struct CoopMem {
+    uint32_t v[8 + kCoopTemps][Q28::N][64];  // values 0-3: point A, 4-7: point B, 8-: temporaries
+    uint32_t slow[64];
+};
+static constexpr int kCoopA = 0, kCoopB = 4, kCoopT = 8;
+
+struct CoopSlot {
+    CoopMem *m;
+    uint32_t s, sb;  // slot of a (and of the temporaries), slot of b
+    int bbase;       // kCoopB, or kCoopA when b is another slot of the same array
+    __device__ __forceinline__ Fq28 ld(int val, uint32_t slot) const {
+        Fq28 r;
+#pragma unroll
+        for (int i = 0; i < Q28::N; i++) r.l[i] = m->v[val][i][slot];
+        return r;
+    }
+    __device__ __forceinline__ void st(int val, const Fq28 &x) {
+#pragma unroll
+        for (int i = 0; i < Q28::N; i++) m->v[val][i][s] = x.l[i];
+    }
+    __device__ __forceinline__ Fq28 a(int i) const { return ld(kCoopA + i, s); }
+    __device__ __forceinline__ Fq28 b(int i) const { return ld(bbase + i, sb); }
+    __device__ __forceinline__ Fq28 t(int i) const { return ld(kCoopT + i, s); }
+    __device__ __forceinline__ void set_a(int i, const Fq28 &x) { st(kCoopA + i, x); }
+    __device__ __forceinline__ void set_t(int i, const Fq28 &x) { st(kCoopT + i, x); }
+    __device__ __forceinline__ bool slow() const { return m->slow[s] != 0; }
+    __device__ __forceinline__ void set_slow(bool f) { m->slow[s] = f ? 1u : 0u; }
+};
+
+__device__ __forceinline__ void coop_store(CoopMem &m, int base, uint32_t slot, const G1Xyzz28 &p) {
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        m.v[base + 0][i][slot] = p.x.l[i];
+        m.v[base + 1][i][slot] = p.y.l[i];
+        m.v[base + 2][i][slot] = p.zz.l[i];
+        m.v[base + 3][i][slot] = p.zzz.l[i];
+    }
+}
+__device__ __forceinline__ G1Xyzz28 coop_load(const CoopMem &m, int base, uint32_t slot) {
+    G1Xyzz28 p;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) {
+        p.x.l[i] = m.v[base + 0][i][slot];
+        p.y.l[i] = m.v[base + 1][i][slot];
+        p.zz.l[i] = m.v[base + 2][i][slot];
+        p.zzz.l[i] = m.v[base + 3][i][slot];
+    }
+    return p;
+}
+__device__ __forceinline__ bool coop_is_identity(const CoopMem &m, int base, uint32_t slot) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) z |= m.v[base + 2][i][slot];
+    return z == 0;
+}
+
+// A[s] += (b_self ? A : B)[s + boff] for the slots s < nact (s + boff < 64).  Called by all 256
+// threads of the block after a barrier that made the operands visible; ends with a barrier.
+// Every wave derives the same per-slot decisions from the same LDS contents, so the branch
+// around the barriers is uniform.
+__device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact) {
+    const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
+    CoopSlot c{&m, s, (s + boff) & 63u, b_self ? kCoopA : kCoopB};
+    const bool act = s < nact;
+    const bool ida = act && coop_is_identity(m, kCoopA, s);
+    const bool idb = !act || coop_is_identity(m, c.bbase, c.sb);
+    const bool live = act && !ida && !idb;
+    __syncthreads();  // every wave has taken its decisions before anything below writes a point
+    if (__any(live)) {
+#pragma unroll 1
+        for (int stage = 0; stage < kCoopAddStages; stage++) {
+            if (live) coop_add_stage(c, stage, (int)w);
+            __syncthreads();
+        }
+    }
+    // what the stages leave to wave 0: equal or opposite points, and a = identity
+    if (w == 0 && act) {
+        if (live && c.slow()) {
+            G1Xyzz28 pa = coop_load(m, kCoopA, s), pb = coop_load(m, c.bbase, c.sb);
+            coop_store(m, kCoopA, s, add_slow_cold(&pa, &pb));
+        } else if (ida && !idb) {
+            coop_store(m, kCoopA, s, coop_load(m, c.bbase, c.sb));
+        }
+    }
+    __syncthreads();
+}
+
+// A[s] <- 2 A[s] in the slots that `want` it; same calling rules as coop_add.
+__device__ __noinline__ void coop_dbl(CoopMem &m, bool want) {
+    const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
+    CoopSlot c{&m, s, s, kCoopA};
+    const bool live = want && !coop_is_identity(m, kCoopA, s);
+    if (__any(live)) {
+#pragma unroll 1
+        for (int stage = 0; stage < kCoopDblStages; stage++) {
+            if (live) coop_dbl_stage(c, stage, (int)w);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
+// Sum of `cnt` points fetched through `at(j)` by a block of exactly 256 threads; valid in thread 0.
+// Every thread first adds up its own strided share; the 256 partial sums are then joined by
+// cooperative additions: three rounds bring the four waves' values into the 64 slots, six more
+// halve the slots.
+template <class At>
+__device__ __forceinline__ G1Xyzz28 block_sum_coop(uint32_t cnt, CoopMem &m, At at) {
+    const uint32_t t = threadIdx.x, w = t >> 6, s = t & 63;
+    G1Xyzz28 acc = xyzz28_identity();
+    for (uint32_t j = t; j < cnt; j += 256) acc = add_inline(acc, *at(j));
+    if (w == 0) coop_store(m, kCoopA, s, acc);
+    for (uint32_t r = 1; r < 4; r++) {
+        if (cnt <= 64 * r) break;  // the later waves hold nothing
+        if (w == r) coop_store(m, kCoopB, s, acc);
+        __syncthreads();
+        coop_add(m, false, 0, 64);
+    }
+    __syncthreads();
+    for (uint32_t off = 32; off > 0; off >>= 1) {
+        if (cnt > off) coop_add(m, true, off, off);
+    }
+    G1Xyzz28 r = coop_load(m, kCoopA, 0);
+    __syncthreads();  // the caller may start the next sum
+    return r;
 }
 
 // Buckets cut into more partials than a lane group handles go to the block path; the queue is
@@ -465,60 +588,69 @@ __global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(const G1Xyzz28 *__r
     if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
 }
 
+// The same with 256 threads per sum and cooperative additions: for bucket arrays small enough that
+// the sums do not fill the GPU anyway.
+__global__ __launch_bounds__(256) void k_row_col_sums_coop(const G1Xyzz28 *__restrict__ B, uint32_t H, uint32_t L,
+                                                           G1Xyzz28 *__restrict__ R, G1Xyzz28 *__restrict__ C) {
+    __shared__ CoopMem mem;
+    const uint32_t i = blockIdx.x;
+    const bool row = i < H;
+    const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
+    const size_t stride = row ? 1 : L;
+    G1Xyzz28 acc = block_sum_coop(row ? L : H, mem, [&](uint32_t j) { return base + (size_t)j * stride; });
+    if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
+}
+
 // block i < lbits: T_i over C; lbits <= i < lbits + hbits: T_i over R; block lbits + hbits: T_all
-__global__ __launch_bounds__(kTreeBlock) void k_bit_sums(const G1Xyzz28 *__restrict__ R, uint32_t hbits,
-                                                         const G1Xyzz28 *__restrict__ C, uint32_t lbits,
-                                                         G1Xyzz28 *__restrict__ T) {
-    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+__global__ __launch_bounds__(256) void k_bit_sums(const G1Xyzz28 *__restrict__ R, uint32_t hbits,
+                                                  const G1Xyzz28 *__restrict__ C, uint32_t lbits,
+                                                  G1Xyzz28 *__restrict__ T) {
+    __shared__ CoopMem mem;
     const uint32_t i = blockIdx.x;
     const bool all = i == lbits + hbits, low = all || i < lbits;
     const G1Xyzz28 *A = low ? C : R;
     const uint32_t nbits = low ? lbits : hbits;
     const uint32_t bit = all ? 31u : (low ? i : i - lbits);
     // j runs over the indices with `bit` removed; put a one back in at that position
-    G1Xyzz28 acc = block_sum(all ? 1u << nbits : 1u << (nbits - 1), sh, [&](uint32_t j) {
+    G1Xyzz28 acc = block_sum_coop(all ? 1u << nbits : 1u << (nbits - 1), mem, [&](uint32_t j) {
         return A + (all ? j : ((((j >> bit) << 1) | 1u) << bit | (j & ((1u << bit) - 1))));
     });
     if (threadIdx.x == 0) T[i] = acc;
 }
 
-// One wave.  Lane d < ndig forms the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2) and doubles
-// it 3d times; lane ndig holds T_all; a shuffle tree adds the ndig + 1 terms:
+// One block of four waves, slot d < ndig for the radix-8 digit U_d = T_3d + 2 T_(3d+1) + 4 T_(3d+2),
+// which is then doubled 3d times; slot ndig holds T_all; a tree adds the ndig + 1 slots:
 //   S = sum_d 8^d U_d + T_all.
-// The doublings of the lanes run side by side, so the chain is 4 + 3 (ndig - 1) short steps and
-// log2(ndig + 1) additions instead of one addition per digit.  Jacobian result.
+// All steps are cooperative (staged) doublings and additions on lazy values.  Jacobian result.
 // For a slice [first, first + 2^sbits) of a larger bucket array (first a multiple of 2^sbits, T the
 // bit sums of the slice, T[sbits] its total) the bits of `first` stand for the whole slice:
 // T_i = T_all for a set bit i >= sbits of first, O for a clear one.
-__global__ __launch_bounds__(64) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t sbits, uint32_t nbits,
-                                               uint32_t first, G1Jac *__restrict__ out) {
-    const uint32_t d = threadIdx.x;
+__global__ __launch_bounds__(256) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t sbits, uint32_t nbits,
+                                                uint32_t first, G1Jac *__restrict__ out) {
+    __shared__ CoopMem m;
+    const uint32_t w = threadIdx.x >> 6, d = threadIdx.x & 63;
     const uint32_t ndig = (nbits + 2) / 3;  // at most 8: nbits <= 23
-    // the per-bit sums arrive in the lazy form; doublings work on canonical values
     auto term = [&](uint32_t bit) {
         if (d >= ndig || bit >= nbits) return xyzz28_identity();
-        if (bit < sbits) return xyzz28_canon(T[bit]);
-        return ((first >> bit) & 1u) ? xyzz28_canon(T[sbits]) : xyzz28_identity();
+        if (bit < sbits) return T[bit];
+        return ((first >> bit) & 1u) ? T[sbits] : xyzz28_identity();
     };
-    G1Xyzz28 acc = term(3 * d + 2);
-    // U_d: (double, add T_(3d+1), double, add T_3d), then 3d doublings in the lanes that need them
-    const uint32_t steps = 4 + 3 * (ndig - 1);
-    for (uint32_t step = 0; step < steps; step++) {
-        const bool dbl = step >= 4 ? step - 4 < 3 * d && d < ndig : (step & 1) == 0;
-        if (dbl) {
-            G1Xyzz28 t = acc;
-            acc = dbl_cold(&t);
-        } else if (step < 4) {
-            acc = add_canonical_inline(acc, term(3 * d + (step == 1 ? 1 : 0)));
-        }
+    if (w == 0) coop_store(m, kCoopA, d, term(3 * d + 2));
+    __syncthreads();
+    for (int k = 1; k >= 0; k--) {
+        coop_dbl(m, d < ndig);
+        if (w == 0) coop_store(m, kCoopB, d, term(3 * d + (uint32_t)k));
+        __syncthreads();
+        coop_add(m, false, 0, ndig);
     }
-    if (d == ndig) acc = T[sbits];  // T_all (lazy form, like every operand of the tree below)
-    for (int off = 8; off > 0; off >>= 1) {
-        G1Xyzz28 o = shfl_down_point(acc, off, 64);
-        if ((int)d >= off || d + off > ndig) o = xyzz28_identity();
-        acc = add_inline(acc, o);
+    for (uint32_t step = 0; step < 3 * (ndig - 1); step++) coop_dbl(m, d < ndig && step < 3 * d);
+    if (w == 0 && d == ndig) coop_store(m, kCoopA, d, T[sbits]);
+    __syncthreads();
+    for (uint32_t off = 8; off > 0; off >>= 1) {
+        // slots s < off whose partner s + off is one of the ndig + 1 terms
+        if (ndig + 1 > off) coop_add(m, true, off, ndig + 1 - off < off ? ndig + 1 - off : off);
     }
-    if (d == 0) *out = xyzz_to_jac(xyzz28_to(xyzz28_canon(acc)));
+    if (threadIdx.x == 0) *out = xyzz_to_jac(xyzz28_to(xyzz28_canon(coop_load(m, kCoopA, 0))));
 }
 
 // B[b] = sum over p of parts[p * count + b]: the bucket partials of `nparts` GPUs for one slice of
@@ -612,10 +744,14 @@ static int reduce_buckets(plonk_hip_ctx *ctx, const G1Xyzz28 *B, uint32_t sbits,
     // one sum per block: wide blocks (small depth) while they are few, one wave per sum once
     // there is a sum for every SIMD (the tree levels of a wide block are mostly idle lanes)
     const uint32_t sums = H + L;
-    const uint32_t width = sums >= 1024 ? 64u : (sums >= 512 ? 128u : 256u);
-    hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, B, H, L, R, C);
-    hipLaunchKernelGGL(k_bit_sums, dim3(sbits + 1), dim3(kTreeBlock), 0, st, R, hbits, C, lbits, T);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, T, sbits, nbits, first, d_out);
+    const uint32_t width = sums >= 1024 ? 64u : 128u;
+    if (sums < 512) {
+        hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums), dim3(256), 0, st, B, H, L, R, C);
+    } else {
+        hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, B, H, L, R, C);
+    }
+    hipLaunchKernelGGL(k_bit_sums, dim3(sbits + 1), dim3(256), 0, st, R, hbits, C, lbits, T);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, T, sbits, nbits, first, d_out);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }

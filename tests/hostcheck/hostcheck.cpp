@@ -9,6 +9,7 @@
 #include "../../plonk_amd/csrc/g1.cuh"
 #include "../../plonk_amd/csrc/field29.cuh"
 #include "../../plonk_amd/csrc/g1_28.cuh"
+#include "../../plonk_amd/csrc/coop28.cuh"
 #include "../../plonk_amd/csrc/msm_core.cuh"
 
 using namespace plonk;
@@ -198,6 +199,66 @@ extern "C" void hc_xyzz28_tree_lazy(const uint32_t *aff, const int *negate, size
         level.swap(next);
     }
     G1Xyzz r = xyzz28_to(xyzz28_canon(level.empty() ? xyzz28_identity() : level[0]));
+    memcpy(out_xyzz, &r, sizeof(r));
+}
+
+// The staged (four-wave) addition and doubling, run on one slot with plain arrays: the stages in
+// order, the four roles one after the other within a stage (what the barriers guarantee).
+struct OneSlot {
+    Fq28 A[4], B[4], T[kCoopTemps];
+    bool flag = false;
+    Fq28 a(int i) const { return A[i]; }
+    Fq28 b(int i) const { return B[i]; }
+    Fq28 t(int i) const { return T[i]; }
+    void set_a(int i, const Fq28 &x) { A[i] = x; }
+    void set_t(int i, const Fq28 &x) { T[i] = x; }
+    bool slow() const { return flag; }
+    void set_slow(bool f) { flag = f; }
+};
+static void slot_put(Fq28 *v, const G1Xyzz28 &p) { v[0] = p.x; v[1] = p.y; v[2] = p.zz; v[3] = p.zzz; }
+static G1Xyzz28 slot_get(const Fq28 *v) { G1Xyzz28 p; p.x = v[0]; p.y = v[1]; p.zz = v[2]; p.zzz = v[3]; return p; }
+static G1Xyzz28 coop_sum(const G1Xyzz28 &a, const G1Xyzz28 &b) {
+    if (xyzz28_is_identity(a)) return b;
+    if (xyzz28_is_identity(b)) return a;
+    OneSlot m;
+    slot_put(m.A, a);
+    slot_put(m.B, b);
+    for (int stage = 0; stage < kCoopAddStages; stage++)
+        for (int w = 0; w < kCoopWaves; w++) coop_add_stage(m, stage, w);
+    if (m.slow()) return xyzz28_add(xyzz28_canon(a), xyzz28_canon(b));
+    return slot_get(m.A);
+}
+static G1Xyzz28 coop_double(const G1Xyzz28 &a) {
+    if (xyzz28_is_identity(a)) return a;
+    OneSlot m;
+    slot_put(m.A, a);
+    for (int stage = 0; stage < kCoopDblStages; stage++)
+        for (int w = 0; w < kCoopWaves; w++) coop_dbl_stage(m, stage, w);
+    return slot_get(m.A);
+}
+// sum of the points by a pairwise tree of staged additions, then `doublings` staged doublings
+extern "C" void hc_xyzz28_tree_coop(const uint32_t *aff, const int *negate, size_t n, int doublings, uint32_t *out_xyzz) {
+    std::vector<G1Xyzz28> level;
+    for (size_t i = 0; i < n; i++) {
+        G1Affine28 p = affine28_from(lda(aff + 24 * i));
+        G1Xyzz28 leaf = xyzz28_identity();
+        if (!affine28_is_identity(p)) {
+            leaf.x = p.x;
+            leaf.y = negate[i] ? q28_neg(p.y) : p.y;
+            leaf.zz = q28_one();
+            leaf.zzz = q28_one();
+        }
+        level.push_back(leaf);
+    }
+    while (level.size() > 1) {
+        std::vector<G1Xyzz28> next;
+        for (size_t i = 0; i + 1 < level.size(); i += 2) next.push_back(coop_sum(level[i], level[i + 1]));
+        if (level.size() & 1) next.push_back(level.back());
+        level.swap(next);
+    }
+    G1Xyzz28 acc = level.empty() ? xyzz28_identity() : level[0];
+    for (int i = 0; i < doublings; i++) acc = coop_double(acc);
+    G1Xyzz r = xyzz28_to(xyzz28_canon(acc));
     memcpy(out_xyzz, &r, sizeof(r));
 }
 

@@ -183,6 +183,16 @@ def test_28_bit_bucket_accumulation(hc):
         lazy = fold_with(hc.hc_xyzz28_fold_lazy, seq)  # the accumulation loop's lazy arithmetic
         tree = fold_with(hc.hc_xyzz28_tree_lazy, seq)  # the tree sums' lazy full additions
         assert o.g1_to_affine(strict) == o.g1_to_affine(lazy) == o.g1_to_affine(tree)
+        # the same tree through the additions staged over four waves, then 5 staged doublings
+        for dbl in (0, 5):
+            a = np.ascontiguousarray(np.stack([x for x, _ in seq]))
+            neg = (ctypes.c_int * len(seq))(*[int(sg) for _, sg in seq])
+            out = np.empty(24, dtype=np.uint64)
+            hc.hc_xyzz28_tree_coop(_p32(a), neg, ctypes.c_size_t(len(seq)), ctypes.c_int(dbl), _p32(out))
+            want = strict
+            for _ in range(dbl):
+                want = o.g1_double(want)
+            assert o.g1_to_affine(_xyzz_to_point(hc, out)) == o.g1_to_affine(want)
         return lazy
 
     rt = np.empty(12, dtype=np.uint64)
