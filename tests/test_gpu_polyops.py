@@ -201,3 +201,41 @@ def test_interpolate_reference_known_answer(backend):
     # coincident points: polynomials.rs:42 `.inverse().unwrap()` panics
     with pytest.raises(plonk_amd.ReferencePanic):
         backend.interpolate_polynomial(M([1, 2, 1]), M([2, 3, 5]))
+
+
+def _rand_mont(rng, n):
+    a = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    a[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)  # below 2^254 < r: a valid Montgomery representative
+    return a
+
+
+def _product_of(vals):
+    """Product of all rows (Montgomery form) by a pairwise tree on the oracle's vector multiply."""
+    one = c.fr_to_mont([1])
+    while len(vals) > 1:
+        if len(vals) & 1:
+            vals = np.concatenate([vals, one])
+        vals = c.fr_mul(vals[0::2].copy(), vals[1::2].copy())
+    return vals[0]
+
+
+def test_quotient_by_2_20_gate_roots(backend):
+    """`compute_q_zero_test_from_roots` (protocols.rs:169-181) at the size of a 2^20-gate circuit:
+    2^20 roots, dividend of 2^22 coefficients.  Size-independent checks: Z(x) = prod (x - rho) at a
+    random x, exact recovery of a known quotient, remainder dropped."""
+    rng = np.random.default_rng(2020)
+    m, nq = 1 << 20, 3 << 20
+    roots = _rand_mont(rng, m)
+    z = backend.construct_vanishing_polynomial_from_roots(roots)
+    assert z.shape == (m + 1, 4) and np.array_equal(z[m], c.fr_to_mont([1])[0])
+    x = _rand_mont(rng, 1)
+    want = _product_of(c.fr_sub(np.repeat(x, m, axis=0), roots))
+    assert np.array_equal(c.fr_eval(z, x[0]), want)
+    q_star = _rand_mont(rng, nq)
+    f = backend.fr_poly_mul(q_star, z)
+    assert f.shape[0] == nq + m
+    assert np.array_equal(c.fr_eval(f, x[0]), c.fr_mul(c.fr_eval(q_star, x[0]).reshape(1, 4), want.reshape(1, 4))[0])
+    got = backend.compute_q_zero_test_from_roots(roots, f)
+    assert np.array_equal(got, q_star)
+    f[:m] = c.fr_add(f[:m].copy(), _rand_mont(rng, m))  # a remainder of degree < m
+    assert np.array_equal(backend.compute_q_zero_test_from_roots(roots, f), q_star)
