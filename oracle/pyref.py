@@ -643,11 +643,76 @@ def load_setup_json(obj):
     return Setup(obj["number_gates"], obj["number_public_inputs"], obj["number_witnesses"], obj["d"], gp)
 
 
-def _selector_and_wiring(setup):
-    """setup_proving_key/mod.rs:32-103 == setup_verification_key/mod.rs:37-105."""
+class Circuit:
+    """A circuit in the trace layout the reference hard-codes for its example (prover/part1.rs:16-59,
+    setup_proving_key/mod.rs:32-103): gate l occupies Omega[3l], Omega[3l+1], Omega[3l+2] (left,
+    right, output), public input i sits at Omega[d-1-i], the witnesses below them.
+        gates[l]   1 = addition, 0 = multiplication                       (the selector S)
+        trace[j]   the value at Omega[j]                                  (the polynomial T)
+        wiring[j]  W(Omega[j]) = Omega[wiring[j]]: cycles through the positions that share a value"""
+
+    def __init__(self, gates, trace, wiring, pub_inputs, output):
+        self.gates, self.trace, self.wiring = list(gates), list(trace), list(wiring)
+        self.pub_inputs, self.output = list(pub_inputs), output
+
+
+def example_circuit(d=12):
+    """The reference's example: inputs 5, 6, witness 1; 5 + 6 = 11, 6 + 1 = 7, 11 * 7 = 77."""
+    trace = [5, 6, 11, 6, 1, 7, 11, 7, 77, 1, 6, 5]
+    src = [d - 2, 1, 3, d - 1, 0, 2, 6, d - 3, 4, 5, 7, 8]
+    dst = [1, 3, d - 2, 0, d - 1, 6, 2, 4, d - 3, 7, 5, 8]
+    wiring = [0] * d
+    for a, b in zip(src, dst):
+        wiring[a] = b
+    return Circuit([1, 1, 0], trace, wiring, [5, 6], 77)
+
+
+def synthetic_circuit(log_gates, seed):
+    """A random circuit of the same family at another size: 2^log_gates - 1 gates, 2 public inputs,
+    1 witness, d = 3 * 2^log_gates (log_gates = 2 gives the example's shape).  Every gate takes two
+    earlier values (inputs, the witness or gate outputs) and adds or multiplies them; the last
+    gate's output is the circuit's output."""
+    import random as _random
+    rnd = _random.Random(seed)
+    ng = (1 << log_gates) - 1
+    d = 3 * ng + 3
+    trace = [0] * d
+    pool = []  # [value, positions]
+    for pos in (d - 1, d - 2, d - 3):
+        v = rnd.randrange(1, R)
+        trace[pos] = v
+        pool.append([v, [pos]])
+    gates = []
+    for l in range(ng):
+        # prefer recent values so that the circuit is a chain, not a star
+        a = pool[max(0, len(pool) - 1 - rnd.randrange(4))] if l else pool[0]
+        b = pool[rnd.randrange(len(pool))] if l else pool[1]
+        kind = rnd.randrange(2)
+        out = (a[0] + b[0]) % R if kind else a[0] * b[0] % R
+        gates.append(kind)
+        for val, pos in ((a, 3 * l), (b, 3 * l + 1)):
+            trace[pos] = val[0]
+            val[1].append(pos)
+        trace[3 * l + 2] = out
+        pool.append([out, [3 * l + 2]])
+    wiring = [0] * d
+    for _, positions in pool:
+        for i, pos in enumerate(positions):
+            wiring[pos] = positions[(i + 1) % len(positions)]
+    return Circuit(gates, trace, wiring, [trace[d - 1], trace[d - 2]], trace[3 * ng - 1])
+
+
+def _selector_and_wiring(setup, circuit=None):
+    """setup_proving_key/mod.rs:32-103 == setup_verification_key/mod.rs:37-105.  Without a circuit:
+    the example, with the reference's literal point lists."""
     d, ng = setup.d, setup.number_gates
     Omega = construct_Omega(d)
     Omega_gates = [Omega[3 * l] for l in range(ng)]
+    if circuit is not None:
+        S = interpolate_polynomial(Omega_gates, circuit.gates)
+        W = interpolate_polynomial(Omega, [Omega[j] for j in circuit.wiring])
+        assert poly_degree(S) == ng - 1 and poly_degree(W) == d - 1
+        return S, W
     gates = [1, 1, 0]
     S = interpolate_polynomial(Omega_gates, gates)
     assert poly_degree(S) == ng - 1
@@ -660,22 +725,26 @@ def _selector_and_wiring(setup):
     return S, W
 
 
-def reproduce_proving_key(setup):
+def reproduce_proving_key(setup, circuit=None):
     """setup_proving_key/mod.rs:23-30,32-103 -> the JSON object of data/proving_key.json."""
-    S, W = _selector_and_wiring(setup)
+    S, W = _selector_and_wiring(setup, circuit)
     return {"S": [fr_to_string(c) for c in S], "W": [fr_to_string(c) for c in W]}
 
 
-def reproduce_verification_key(setup):
+def reproduce_verification_key(setup, circuit=None):
     """setup_verification_key/mod.rs:23-35,37-113 -> the JSON object of
     data/verification_key.json."""
-    S, W = _selector_and_wiring(setup)
+    S, W = _selector_and_wiring(setup, circuit)
     return {"com_S": g1_hex(kzg_commit(setup.gp, S)), "com_W": g1_hex(kzg_commit(setup.gp, W))}
 
 
-def prover_part1(setup, Omega):
+def prover_part1(setup, Omega, circuit=None):
     """prover/part1.rs:9-69."""
     d = setup.d
+    if circuit is not None:
+        T = interpolate_polynomial(Omega, circuit.trace)
+        assert poly_degree(T) == d - 1
+        return T, kzg_commit(setup.gp, T)
     xs = [Omega[d - 1], Omega[d - 2], Omega[d - 3]] + [Omega[i] for i in range(9)]
     ys = [5, 6, 1, 5, 6, 11, 6, 1, 7, 11, 7, 77]
     T = interpolate_polynomial(xs, ys)
@@ -690,7 +759,7 @@ def prover_part2(setup, pub_inputs, Omega, T, com_T):
     v = interpolate_polynomial(Omega_inputs, pub_inputs)
     assert poly_degree(v) == setup.number_public_inputs - 1
     T_minus_v = poly_sub(T, v)
-    assert poly_degree(T_minus_v) == 11
+    assert poly_degree(T_minus_v) == d - 1  # 11 in the example (part2.rs)
     com_v = kzg_commit(gp, v)
     com_T_minus_v = g1_sub(com_T, com_v)
     q = compute_q_zero_test_from_roots(Omega_inputs, T_minus_v)
@@ -764,17 +833,18 @@ def proof_to_json(pub_inputs, output, com_T, p2, p3, p4, p5):
     }
 
 
-def reproduce_proof(setup, proving_key_json, verification_key_json):
+def reproduce_proof(setup, proving_key_json, verification_key_json, circuit=None):
     """prover/mod.rs:18-74 driven from the three input JSON objects read by
-    bin/prover.rs:10-38 -> the JSON object of data/proof.json."""
+    bin/prover.rs:10-38 -> the JSON object of data/proof.json.  Without a circuit: the example
+    (inputs 5, 6 and output 77 as hard-coded at prover/mod.rs:25-26)."""
     S = poly_trim([int(x) for x in proving_key_json["S"]])
     W = poly_trim([int(x) for x in proving_key_json["W"]])
     com_S = g1_decompress(bytes.fromhex(verification_key_json["com_S"]))
     com_W = g1_decompress(bytes.fromhex(verification_key_json["com_W"]))
-    pub_inputs = [5, 6]
-    output = 77
+    pub_inputs = [5, 6] if circuit is None else circuit.pub_inputs
+    output = 77 if circuit is None else circuit.output
     Omega = construct_Omega(setup.d)
-    T, com_T = prover_part1(setup, Omega)
+    T, com_T = prover_part1(setup, Omega, circuit)
     p2 = prover_part2(setup, pub_inputs, Omega, T, com_T)
     p3 = prover_part3(setup, S, com_S, Omega, T, com_T)
     p4 = prover_part4(setup, W, com_W, Omega, T, com_T)

@@ -34,12 +34,11 @@ def test_example_proof_bytes_through_gpu(backend, golden, monkeypatch):
     assert calls == {"commit": 2 + 6, "open": 15}
 
 
-def test_example_proof_bytes_with_the_polynomial_layer_on_the_gpu(backend, golden, monkeypatch):
-    """The same proof, now with interpolation, f(wX), products and both quotients of
-    common/polynomials.rs and common/protocols.rs also computed on the GPU (the gadget logic,
-    the challenges and the JSON stay with the restatement)."""
-    setup = o.load_setup_json(golden["srs"])
-    backend.srs_load_projective(c.g1_to_limbs(setup.gp.tau_powers_g1))
+def _polynomial_layer_on_gpu(backend, monkeypatch):
+    """Replaces the restatement's commitments, openings, interpolation, f(wX), products and both
+    quotients (common/kzg.rs, common/polynomials.rs, common/protocols.rs) by calls through the C
+    ABI; the gadget logic, the challenges and the JSON stay with the restatement.  Returns the call
+    counters."""
     calls = {k: 0 for k in ("commit", "open", "interpolate_omega", "interpolate", "shift", "mul", "div_vanishing",
                             "div_roots")}
     M, U = c.fr_to_mont, c.fr_from_mont
@@ -56,7 +55,7 @@ def test_example_proof_bytes_with_the_polynomial_layer_on_the_gpu(backend, golde
 
     def gpu_interpolate(xs, ys):
         n = len(xs)
-        if list(xs) == o.construct_Omega(n):
+        if n > 1 and (o.R - 1) % n == 0 and list(xs) == o.construct_Omega(n):
             calls["interpolate_omega"] += 1
             return o.poly_trim(U(backend.fr_ntt_mixed(M(ys), inverse=True)))
         calls["interpolate"] += 1
@@ -90,9 +89,62 @@ def test_example_proof_bytes_with_the_polynomial_layer_on_the_gpu(backend, golde
     monkeypatch.setattr(o, "poly_mul", gpu_mul)
     monkeypatch.setattr(o, "compute_q_zero_test", gpu_q_vanishing)
     monkeypatch.setattr(o, "compute_q_zero_test_from_roots", gpu_q_roots)
+    return calls
+
+
+def test_example_proof_bytes_with_the_polynomial_layer_on_the_gpu(backend, golden, monkeypatch):
+    """The same proof, now with interpolation, f(wX), products and both quotients of
+    common/polynomials.rs and common/protocols.rs also computed on the GPU."""
+    setup = o.load_setup_json(golden["srs"])
+    backend.srs_load_projective(c.g1_to_limbs(setup.gp.tau_powers_g1))
+    calls = _polynomial_layer_on_gpu(backend, monkeypatch)
     assert o.reproduce_proving_key(setup) == golden["proving_key"]
     assert o.reproduce_verification_key(setup) == golden["verification_key"]
     proof = o.reproduce_proof(setup, golden["proving_key"], golden["verification_key"])
     assert proof == golden["proof"]
     assert calls["commit"] == 8 and calls["open"] == 15
     assert min(calls.values()) > 0, calls
+
+
+def _synthetic_setup(backend, log_gates, seed):
+    circuit = o.synthetic_circuit(log_gates, seed)
+    d = len(circuit.trace)
+    tau = 0x0123456789ABCDEF0FEDCBA987654321 + seed
+    # the quotient of the gate check has degree 2d - 3 (setup_global_params/mod.rs:60-61: 21 for d = 12)
+    pts = backend.kzg_setup(c.fr_to_mont([tau])[0], 2 * d - 3)
+    return circuit, d, tau, pts
+
+
+@pytest.mark.parametrize("log_gates", [3, 5])
+def test_synthetic_circuit_proof_matches_the_restatement(backend, monkeypatch, log_gates):
+    """Larger circuits of the example's family (2^k - 1 gates, d = 3 * 2^k trace rows): the whole
+    proof computed through the C ABI equals the restatement's, field by field."""
+    circuit, d, tau, pts = _synthetic_setup(backend, log_gates, 11)
+    setup = o.Setup((1 << log_gates) - 1, 2, 1, d, o.GlobalParameters(c.g1_from_limbs(pts), b""))
+    pk = o.reproduce_proving_key(setup, circuit)
+    vk = o.reproduce_verification_key(setup, circuit)
+    want = o.reproduce_proof(setup, pk, vk, circuit)
+    calls = _polynomial_layer_on_gpu(backend, monkeypatch)
+    assert o.reproduce_proving_key(setup, circuit) == pk
+    assert o.reproduce_verification_key(setup, circuit) == vk
+    assert o.reproduce_proof(setup, pk, vk, circuit) == want
+    assert calls["commit"] == 8 and calls["open"] == 15 and min(calls.values()) > 0, calls
+
+
+def test_synthetic_circuit_of_255_gates(backend, monkeypatch):
+    """d = 768 rows, beyond what the quadratic and cubic loops of the restatement finish quickly: the
+    GPU-backed prover alone, checked by the prover's own assertions (the gate constraint vanishes on
+    the gate rows, the wiring holds on Omega, t1 = q * Z_Omega exactly, the opening at the last gate
+    gives the output) and by commit == [f(tau)]G for the trace."""
+    log_gates = 8
+    circuit, d, tau, pts = _synthetic_setup(backend, log_gates, 12)
+    setup = o.Setup((1 << log_gates) - 1, 2, 1, d, o.GlobalParameters([None] * (2 * d - 2), b""))
+    calls = _polynomial_layer_on_gpu(backend, monkeypatch)
+    pk = o.reproduce_proving_key(setup, circuit)
+    vk = o.reproduce_verification_key(setup, circuit)
+    proof = o.reproduce_proof(setup, pk, vk, circuit)
+    assert proof["output"] == o.fr_to_string(circuit.output)
+    T = o.interpolate_polynomial(o.construct_Omega(d), circuit.trace)
+    want = o.g1_mul(o.G1_GENERATOR, o.poly_eval(T, tau))
+    assert proof["com_T"] == o.g1_hex(want)
+    assert calls["open"] == 15

@@ -128,3 +128,26 @@ def test_transforms_match_reference_definitions():
         assert ev == [o.poly_eval(co, x) for x in Om]          # protocols.rs:243-250
         assert o.interpolate_polynomial(Om, ev) == o.poly_trim(co)  # polynomials.rs:50-58
         assert o.ntt(ev, invert=True) == co
+
+
+def test_example_as_a_circuit_description_reproduces_the_golden_files(golden):
+    setup = o.load_setup_json(golden["srs"])
+    ex = o.example_circuit()
+    assert o.reproduce_proving_key(setup, ex) == golden["proving_key"]
+    assert o.reproduce_verification_key(setup, ex) == golden["verification_key"]
+    assert o.reproduce_proof(setup, golden["proving_key"], golden["verification_key"], ex) == golden["proof"]
+
+
+def test_synthetic_circuit_family_proves():
+    # 7 gates, d = 24: the prover's own assertions (gate constraint, wiring, divisibility, output) hold
+    circuit = o.synthetic_circuit(3, 5)
+    d = len(circuit.trace)
+    assert d == 24 and len(circuit.gates) == 7 and sorted(circuit.wiring) == list(range(d))
+    for l, kind in enumerate(circuit.gates):
+        a, b, out = circuit.trace[3 * l:3 * l + 3]
+        assert out == ((a + b) if kind else a * b) % o.R
+    setup = o.Setup(7, 2, 1, d, o.kzg_setup_with_tau(2 * d - 3, 0x1234567))
+    pk, vk = o.reproduce_proving_key(setup, circuit), o.reproduce_verification_key(setup, circuit)
+    proof = o.reproduce_proof(setup, pk, vk, circuit)
+    assert proof["output"] == o.fr_to_string(circuit.output)
+    assert len(proof["proof_T_W_prescribed_permutation"]) == 16
