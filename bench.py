@@ -30,7 +30,7 @@ import numpy as np
 MADS_PER_POINT = 16 * 10 * 300
 # k_accumulate, 2^24 points on one GPU: 2 x FETCH_SIZE (gfx950 counts 128-byte requests as 64 bytes;
 # checked on the gather microbenchmark) + WRITE_SIZE, averaged over the launches of one bench run
-PMC_TRAFFIC_BYTES = int((2 * 14267347 + 783653) * 1024)
+PMC_TRAFFIC_BYTES = int((2 * 14268448 + 783653) * 1024)
 
 
 def hbm_view(be, n_local, windows, acc_ms):
@@ -291,7 +291,7 @@ def main():
                         "launch / average k_accumulate duration (HIP events on the library stream); peak = "
                         "v_mad_u64_u32 register-only microbenchmark run in this process; traffic = bytes per "
                         "launch from the committed rocprofv3 counter pass (2 x FETCH_SIZE + WRITE_SIZE, "
-                        "profiles/r01_e_pmc_per_kernel.csv)",
+                        "profiles/r01_g_pmc_per_kernel.csv)",
                 "kernel_ms": round(acc_ms, 3),
                 "hbm_view": hbm_view(be, n_local, plan["windows"], acc_ms),
             },
