@@ -257,6 +257,14 @@ int plonk_hip_fr_prefix_sum(plonk_hip_ctx *ctx, uint64_t *data, size_t n);
 /* data[i] <- 1 / data[i]; PLONK_HIP_ERR_ZERO_DENOMINATOR if some element is zero (data is then
  * unspecified), where the reference panics on `.inverse().unwrap()` (protocols.rs:349, 583). */
 int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n);
+/* out[i] = a * x[i] + b * y[i] + (i == 0 || broadcast ? c : 0) for i < max(nx, ny), coefficients past
+ * the end of x or y counting as zero: the sums, differences and scalar multiples of dense polynomials
+ * that the gadgets form inline (`&f + &g`, `&f - &g`, `r - s W - f`: protocols.rs:272, 382, 490, 583-584,
+ * 620-635, 736-749; prover/part2.rs:45, part3.rs:56-59), and with broadcast = 1 the same on value
+ * vectors over Omega (numerators and denominators of protocols.rs:578-582).  a, b, c: 4 limbs each. */
+int plonk_hip_fr_linear_combination(plonk_hip_ctx *ctx, const uint64_t *x, size_t nx, const uint64_t *y, size_t ny,
+                                    const uint64_t a[4], const uint64_t b[4], const uint64_t c[4], int broadcast,
+                                    uint64_t *out /* max(nx, ny) x 4 */);
 /* out[i] = prod_{j<=i} num[j] / den[j]: the t values of the rational product check and of the
  * prescribed-permutation check (protocols.rs:345-353, 571-588). */
 int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, const uint64_t *den, size_t n,

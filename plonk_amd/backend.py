@@ -358,6 +358,18 @@ class Backend:
         self._check(self._lib.plonk_hip_fr_batch_inverse(self._ctx, _u64(d), d.shape[0]))
         return d
 
+    def fr_linear_combination(self, x, y, a, b, c, broadcast=False):
+        """a*x + b*y + c (c on coefficient 0 only, or on every element with broadcast): x, y dense
+        coefficient or value vectors of any lengths; a, b, c field elements (4 limbs)."""
+        x, y = _fr(x), _fr(y)
+        n = max(x.shape[0], y.shape[0])
+        out = np.empty((n, 4), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_fr_linear_combination(
+            self._ctx, _u64(x) if x.shape[0] else None, x.shape[0], _u64(y) if y.shape[0] else None, y.shape[0],
+            _u64(_fr(a).reshape(4)), _u64(_fr(b).reshape(4)), _u64(_fr(c).reshape(4)), 1 if broadcast else 0,
+            _u64(out) if n else None))
+        return out
+
     def fr_ratio_prefix_product(self, num, den):
         """t_i = prod_{j<=i} num_j / den_j (protocols.rs:345-353, 571-588)."""
         num, den = _fr(num), _fr(den)

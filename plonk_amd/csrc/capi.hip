@@ -626,6 +626,25 @@ int plonk_hip_fr_batch_inverse(plonk_hip_ctx *ctx, uint64_t *data, size_t n) {
     return download(ctx, data, d, n);
 }
 
+int plonk_hip_fr_linear_combination(plonk_hip_ctx *ctx, const uint64_t *x, size_t nx, const uint64_t *y, size_t ny,
+                                    const uint64_t a[4], const uint64_t b[4], const uint64_t c[4], int broadcast,
+                                    uint64_t *out) {
+    PLONK_ENTER(ctx);
+    const size_t n = nx > ny ? nx : ny;
+    if (!a || !b || !c || (!x && nx) || (!y && ny) || (!out && n)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    Fr *d_x = nullptr, *d_y = nullptr;
+    if (nx) PLONK_TRY(upload(ctx, ctx->scalars_stage, x, nx, n, &d_x));
+    if (ny) PLONK_TRY(upload(ctx, ctx->scratch_c, y, ny, n, &d_y));
+    Fr fa, fb, fc;
+    memcpy(&fa, a, sizeof(Fr));
+    memcpy(&fb, b, sizeof(Fr));
+    memcpy(&fc, c, sizeof(Fr));
+    Fr *d_out = nx >= ny ? d_x : d_y;  // the longer operand's buffer holds n elements
+    PLONK_TRY(linear_combination(ctx, d_x, nx, d_y, ny, fa, fb, fc, broadcast != 0, d_out));
+    return download(ctx, out, d_out, n);
+}
+
 int plonk_hip_fr_ratio_prefix_product(plonk_hip_ctx *ctx, const uint64_t *num, const uint64_t *den, size_t n,
                                       uint64_t *out) {
     PLONK_ENTER(ctx);

@@ -19,6 +19,9 @@ int prefix_scan(plonk_hip_ctx *ctx, Fr *d, size_t n, bool product, Fr *d_scratch
 // element-wise inverse in place; *d_flag (device int, cleared by the caller) becomes 1 on a zero element
 int batch_inverse(plonk_hip_ctx *ctx, Fr *d, size_t n, int *d_flag);
 int pointwise_mul(plonk_hip_ctx *ctx, const Fr *a, const Fr *b, Fr *out, size_t count);
+// out[i] = a x[i] + b y[i] + (i == 0 || broadcast ? c : 0), i < max(nx, ny)
+int linear_combination(plonk_hip_ctx *ctx, const Fr *x, size_t nx, const Fr *y, size_t ny, const Fr &a, const Fr &b,
+                       const Fr &c, bool broadcast, Fr *out);
 // out[j] = sum_t f[j + t*k], j < k
 int fold_mod_vanishing(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, size_t k, Fr *d_out);
 // out[i] = f(points[i])

@@ -175,6 +175,27 @@ int pointwise_mul(plonk_hip_ctx *ctx, const Fr *a, const Fr *b, Fr *out, size_t 
     return PLONK_HIP_OK;
 }
 
+// out[i] = a x[i] + b y[i] + (i == 0 || broadcast ? c : 0) for i < max(nx, ny); coefficients past
+// the end of x or y read as zero.  out may be x or y.
+__global__ __launch_bounds__(256) void k_linear_combination(const Fr *x, size_t nx, const Fr *y, size_t ny, Fr a, Fr b,
+                                                            Fr c, int broadcast, Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (nx > ny ? nx : ny)) return;
+    Fr v = (i == 0 || broadcast) ? c : fe_zero<FrCfg>();
+    if (i < nx) v = fe_add(v, fe_mul(a, x[i]));
+    if (i < ny) v = fe_add(v, fe_mul(b, y[i]));
+    out[i] = v;
+}
+
+int linear_combination(plonk_hip_ctx *ctx, const Fr *x, size_t nx, const Fr *y, size_t ny, const Fr &a, const Fr &b,
+                       const Fr &c, bool broadcast, Fr *out) {
+    const size_t n = nx > ny ? nx : ny;
+    if (n)
+        hipLaunchKernelGGL(k_linear_combination, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, x, nx, y, ny, a, b, c,
+                           broadcast ? 1 : 0, out);
+    return PLONK_HIP_OK;
+}
+
 // out[j] = sum_t f[j + t*k], j < k: the residue of f modulo X^k - 1 (same values on the k-th roots of unity)
 __global__ __launch_bounds__(256) void k_fold(const Fr *__restrict__ f, size_t n, size_t k, Fr *__restrict__ out) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

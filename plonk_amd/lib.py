@@ -88,6 +88,9 @@ SIGNATURES = {
     "plonk_hip_fr_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
     "plonk_hip_fr_prefix_sum": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
     "plonk_hip_fr_batch_inverse": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
+    "plonk_hip_fr_linear_combination": (
+        ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p, c_u64p, ctypes.c_int,
+                       c_u64p]),
     "plonk_hip_fr_ratio_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_poly_mul": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),

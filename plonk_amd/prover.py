@@ -1,0 +1,326 @@
+"""Host side of the prover on limb arrays: `setup_proving_key`, `setup_verification_key` and
+`prover::run` of the reference (plonk/src/setup_proving_key/mod.rs:32-103,
+plonk/src/setup_verification_key/mod.rs:37-113, plonk/src/prover/mod.rs:18-74, part1-5.rs) with every
+polynomial and every group operation done by the HIP library through `Backend`.
+
+Polynomials and value vectors are (n, 4) uint64 arrays of Montgomery limbs (the memory layout of
+`Vec<Fr>`) from end to end; Python integers appear only for the handful of scalars of a proof
+(challenges, opened values, the two coefficients of v).  The reference hard-codes its 3-gate example;
+this module takes the circuit as data in the same trace layout (gate l on rows 3l, 3l+1, 3l+2 of
+Omega, public input i on row d-1-i, witnesses below them) for any d = 3 * 2^k or 2^k that divides
+r - 1.  The example is `example_circuit()`.
+
+Nothing here falls back to a CPU implementation: without the HIP library `Backend` cannot be
+constructed."""
+import hashlib
+
+import numpy as np
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+FR_GENERATOR = 7  # ark_bls12_381::Fr::GENERATOR (common/utils.rs:20-21)
+_MONT = (1 << 256) % R_MOD
+_MONT_INV = pow(_MONT, -1, R_MOD)
+
+
+# ------------------------------------------------------------------------------ scalars <-> limbs
+def to_mont(values):
+    """Python integers -> (n, 4) Montgomery limbs."""
+    raw = b"".join((v % R_MOD * _MONT % R_MOD).to_bytes(32, "little") for v in values)
+    return np.frombuffer(raw, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def from_mont(limbs):
+    """(n, 4) or (4,) Montgomery limbs -> list of canonical Python integers."""
+    raw = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4).tobytes()
+    return [int.from_bytes(raw[i:i + 32], "little") * _MONT_INV % R_MOD for i in range(0, len(raw), 32)]
+
+
+def _m(value):
+    return to_mont([value])[0]
+
+
+def trim(poly):
+    """Drops trailing zero coefficients (ark's DensePolynomial invariant)."""
+    nz = np.flatnonzero(poly.any(axis=1))
+    return poly[: (int(nz[-1]) + 1 if nz.size else 0)]
+
+
+def root_of_unity(n):
+    """omega of `construct_Omega(n)` (common/utils.rs:11-38)."""
+    if n < 2 or (R_MOD - 1) % n:
+        raise ValueError("k must divide r - 1 (multiplicative group order)")
+    return pow(FR_GENERATOR, (R_MOD - 1) // n, R_MOD)
+
+
+# ------------------------------------------------------------------------------ circuit description
+class Circuit:
+    """gates[l]: 1 addition, 0 multiplication; trace: (d, 4) limbs, the value on every row of Omega;
+    wiring: (d,) integers, W(Omega[j]) = Omega[wiring[j]]; pub_inputs, output: integers."""
+
+    def __init__(self, gates, trace, wiring, pub_inputs, output):
+        self.gates = np.asarray(gates, dtype=np.uint8)
+        self.trace = np.ascontiguousarray(trace, dtype=np.uint64).reshape(-1, 4)
+        self.wiring = np.asarray(wiring, dtype=np.int64)
+        self.pub_inputs = [int(x) for x in pub_inputs]
+        self.output = int(output)
+        self.d = self.trace.shape[0]
+        self.number_gates = self.gates.shape[0]
+        if self.wiring.shape[0] != self.d or 3 * self.number_gates + len(self.pub_inputs) > self.d:
+            raise ValueError("circuit does not fit its trace")
+
+
+def example_circuit():
+    """The reference's circuit (prover/part1.rs:16-59, setup_proving_key/mod.rs:45-95): inputs 5, 6,
+    witness 1; 5 + 6 = 11, 6 + 1 = 7, 11 * 7 = 77."""
+    d = 12
+    src = [d - 2, 1, 3, d - 1, 0, 2, 6, d - 3, 4, 5, 7, 8]
+    dst = [1, 3, d - 2, 0, d - 1, 6, 2, 4, d - 3, 7, 5, 8]
+    wiring = [0] * d
+    for a, b in zip(src, dst):
+        wiring[a] = b
+    return Circuit([1, 1, 0], to_mont([5, 6, 11, 6, 1, 7, 11, 7, 77, 1, 6, 5]), wiring, [5, 6], 77)
+
+
+def synthetic_circuit(log_gates, seed):
+    """A random circuit of the example's family: 2^log_gates - 1 gates, 2 public inputs, 1 witness,
+    d = 3 * 2^log_gates rows.  Every gate adds or multiplies two earlier values."""
+    import random
+    rnd = random.Random(seed)
+    ng = (1 << log_gates) - 1
+    d = 3 * ng + 3
+    trace = [0] * d
+    values, positions = [], []
+    for pos in (d - 1, d - 2, d - 3):
+        v = rnd.randrange(1, R_MOD)
+        trace[pos] = v
+        values.append(v)
+        positions.append([pos])
+    gates = []
+    for l in range(ng):
+        ia = max(0, len(values) - 1 - rnd.randrange(4)) if l else 0
+        ib = rnd.randrange(len(values)) if l else 1
+        kind = rnd.randrange(2)
+        out = (values[ia] + values[ib]) % R_MOD if kind else values[ia] * values[ib] % R_MOD
+        gates.append(kind)
+        for idx, pos in ((ia, 3 * l), (ib, 3 * l + 1)):
+            trace[pos] = values[idx]
+            positions[idx].append(pos)
+        trace[3 * l + 2] = out
+        values.append(out)
+        positions.append([3 * l + 2])
+    wiring = [0] * d
+    for plist in positions:
+        for i, pos in enumerate(plist):
+            wiring[pos] = plist[(i + 1) % len(plist)]
+    return Circuit(gates, to_mont(trace), wiring, [trace[d - 1], trace[d - 2]], trace[3 * ng - 1])
+
+
+# ------------------------------------------------------------------------------ the prover
+class Prover:
+    """One circuit size on one GPU.  `setup(tau)` stands for setup_global_params (the SRS stays on
+    the device), `keys(circuit)` for setup_proving_key + setup_verification_key, `prove(circuit, keys)`
+    for prover::run; the proof comes back as the dictionary `ProofJson` serialises
+    (common/proof.rs:58-268)."""
+
+    def __init__(self, backend, d):
+        self.be = backend
+        self.d = d
+        self.w = root_of_unity(d)
+        self.one = _m(1)
+        self.zero = np.zeros(4, dtype=np.uint64)
+        # Omega as limbs: the powers of w (f(wX) of the all-ones polynomial)
+        self.omega = backend.compose_with_scaling(np.tile(self.one, (d, 1)), _m(self.w))
+
+    # -- helpers -----------------------------------------------------------------------------
+    def setup(self, tau):
+        """`kzg_setup(2d - 3)` (setup_global_params/mod.rs:60-61: 21 for d = 12)."""
+        self.be.kzg_setup(_m(tau), 2 * self.d - 3, want_points=False)
+
+    def _transform(self, data, inverse):
+        if self.d & (self.d - 1) == 0:
+            return self.be.fr_ntt(data, inverse=inverse)
+        return self.be.fr_ntt_mixed(data, inverse=inverse)
+
+    def interpolate_over_omega(self, values):
+        return trim(self._transform(values, True))
+
+    def evaluate_over_omega(self, poly):
+        padded = np.zeros((self.d, 4), dtype=np.uint64)
+        padded[: poly.shape[0]] = poly
+        return self._transform(padded, False)
+
+    def lin(self, x, y, a, b, c=0, broadcast=False):
+        return self.be.fr_linear_combination(x, y, _m(a), _m(b), _m(c), broadcast)
+
+    def shift(self, poly, factor):
+        """f(factor * X) (`compose_polynomials(f, [0, factor])`)."""
+        return self.be.compose_with_scaling(poly, _m(factor))
+
+    def mul(self, a, b):
+        return trim(self.be.fr_poly_mul(a, b))
+
+    def hex_of(self, point):
+        return bytes(self.be.g1_compress(np.asarray(point).reshape(1, 18))[0]).hex()
+
+    def challenge(self, points, count=None):
+        """common/utils.rs:65-82 (one challenge) and :85-117 (several): Blake2s-256 over the compressed
+        commitments, digests read little-endian mod r."""
+        h = hashlib.blake2s()
+        for p in points:
+            h.update(bytes(self.be.g1_compress(np.asarray(p).reshape(1, 18))[0]))
+        if count is None:
+            return int.from_bytes(h.digest(), "little") % R_MOD
+        base = h.digest()
+        out = []
+        for i in range(count):
+            sub = hashlib.blake2s()
+            sub.update(base)
+            sub.update(bytes([i & 0xFF]))
+            out.append(int.from_bytes(sub.digest(), "little") % R_MOD)
+        return out
+
+    def open(self, poly, point):
+        v, proof = self.be.kzg_evaluate(poly, _m(point))
+        return from_mont(v)[0], proof
+
+    def _subtract_points(self, p, q):
+        """p - q for two Jacobian points in limb form (`com_T - com_v`, prover/part2.rs:49)."""
+        neg = np.array(q, dtype=np.uint64).reshape(18)
+        y = int.from_bytes(neg[6:12].tobytes(), "little")
+        neg[6:12] = np.frombuffer(((Q_MOD - y) % Q_MOD).to_bytes(48, "little"), dtype=np.uint64)
+        d_in = self.be.to_device(np.stack([np.asarray(p, dtype=np.uint64).reshape(18), neg]))
+        d_out = self.be.malloc(144)
+        self.be.g1_sum_dev(d_in, 2, d_out)
+        self.be.sync()
+        out = self.be.from_device(d_out, (18,))
+        self.be.free(d_in)
+        self.be.free(d_out)
+        return out
+
+    # -- setup_proving_key / setup_verification_key ------------------------------------------
+    def selector(self, circuit):
+        """S = interpolate(Omega_gates, gates), degree < number_gates (setup_proving_key/mod.rs:36-43).
+        The gate rows Omega[3l] lie in the subgroup generated by w^3; when they are all of it but
+        one row (the family of the example) the missing value is the one that makes the top
+        coefficient of the subgroup interpolant vanish, and one inverse transform gives S."""
+        ng, d = circuit.number_gates, self.d
+        n = ng + 1
+        if d % 3 or d // 3 != n or n & (n - 1):
+            xs = self.omega[0:3 * ng:3]
+            return trim(self.be.interpolate_polynomial(xs, to_mont([int(g) for g in circuit.gates])))
+        w3 = pow(self.w, 3, R_MOD)
+        powers = self.be.compose_with_scaling(np.tile(self.one, (n, 1)), _m(w3))
+        values = np.zeros((n, 4), dtype=np.uint64)
+        values[:ng][circuit.gates != 0] = self.one
+        # top coefficient = (1/n) sum_j y_j w3^j; solve for y_ng
+        masked = np.zeros((n, 4), dtype=np.uint64)
+        masked[:ng][circuit.gates != 0] = powers[:ng][circuit.gates != 0]
+        total = from_mont(self.be.fr_prefix_sum(masked)[n - 1])[0]
+        missing = (-total) * pow(pow(w3, ng, R_MOD), -1, R_MOD) % R_MOD
+        values[ng] = _m(missing)
+        s_poly = self.be.fr_ntt(values, inverse=True)
+        assert not s_poly[n - 1].any()
+        return trim(s_poly)
+
+    def keys(self, circuit):
+        """S, W and their commitments (setup_proving_key/mod.rs:32-103, setup_verification_key/mod.rs:
+        37-113)."""
+        S = self.selector(circuit)
+        W = self.interpolate_over_omega(self.omega[circuit.wiring])
+        com = self.be.kzg_commit_batch([S, W])
+        return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
+
+    # -- prover::run ---------------------------------------------------------------------------
+    def prove(self, circuit, keys):
+        be, d, w = self.be, self.d, self.w
+        ng = circuit.number_gates
+        S, W = keys["S"], keys["W"]
+        # part 1 (prover/part1.rs:9-69)
+        T = self.interpolate_over_omega(circuit.trace)
+        if T.shape[0] != d:
+            raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
+        com_T = be.kzg_commit(T)
+
+        # part 2 (prover/part2.rs:14-61): T - v vanishes on the public-input rows
+        n_in = len(circuit.pub_inputs)
+        rows_in = [pow(w, d - 1 - i, R_MOD) for i in range(n_in)]
+        v = trim(be.interpolate_polynomial(to_mont(rows_in), to_mont(circuit.pub_inputs)))
+        T_minus_v = trim(self.lin(T, v, 1, -1))
+        com_v = be.kzg_commit(v)
+        com_T_minus_v = self._subtract_points(com_T, com_v)
+        q2 = trim(be.compute_q_zero_test_from_roots(to_mont(rows_in), T_minus_v))
+        r2 = self.challenge([com_T_minus_v])
+        p2 = {"com_q": be.kzg_commit(q2)}
+        p2["f_r"], p2["proof_f_r"] = self.open(T_minus_v, r2)
+        p2["q_r"], p2["proof_q_r"] = self.open(q2, r2)
+
+        # part 3 (prover/part3.rs:16-75, protocols.rs:722-786): the gate constraint
+        T_w = self.shift(T, w)
+        T_w2 = self.shift(T, w * w % R_MOD)
+        one_minus_S = self.lin(S, S[:0], -1, 0, 1)
+        S_T = self.lin(self.lin(self.mul(S, self.lin(T, T_w, 1, 1)),
+                                self.mul(one_minus_S, self.mul(T, T_w)), 1, 1), T_w2, 1, -1)
+        S_T = trim(S_T)
+        rows_gates = self.omega[0:3 * ng:3]
+        q3 = trim(be.compute_q_zero_test_from_roots(rows_gates, S_T))
+        r3 = self.challenge([com_T, keys["com_S"]])
+        p3 = {"com_q": be.kzg_commit(q3)}
+        vs, proofs = be.kzg_evaluate_many(T, to_mont([r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD]))
+        vs = from_mont(vs)
+        p3["T_r"], p3["T_w_r"], p3["T_w2_r"] = vs
+        p3["proof_T_r"], p3["proof_T_w_r"], p3["proof_T_w2_r"] = proofs
+        p3["S_r"], p3["proof_S_r"] = self.open(S, r3)
+        p3["q_r"], p3["proof_q_r"] = self.open(q3, r3)
+
+        # part 4 (prover/part4.rs:17-66, protocols.rs:559-687): the wiring, T(W(y)) = T(y) on Omega
+        r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
+        T_vals = self.evaluate_over_omega(T)
+        W_vals = self.evaluate_over_omega(W)
+        num = self.lin(W_vals, T_vals, -s, -1, r, broadcast=True)   # r - s W(x) - f(x)
+        den = self.lin(self.omega, T_vals, -s, -1, r, broadcast=True)  # r - s x - g(x)
+        t = self.interpolate_over_omega(be.fr_ratio_prefix_product(num, den))
+        if t.shape[0] != d:
+            raise NotImplementedError("extra random interpolation points (protocols.rs:589-600) are not drawn here")
+        t_w = self.shift(t, w)
+        left = self.lin(to_mont([r, (-s * w) % R_MOD]), T_w, 1, -1)      # r - s w X - g(wX)
+        right = self.lin(self.shift(W, w), T_w, -s, -1, r)                 # r - s W(wX) - f(wX)
+        t1 = trim(self.lin(self.mul(t_w, left), self.mul(t, right), 1, -1))
+        q4 = trim(be.compute_q_zero_test(d, t1))
+        p4 = {}
+        com = be.kzg_commit_batch([t, q4])
+        p4["com_t"], p4["com_q"] = com[0], com[1]
+        vs, proofs = be.kzg_evaluate_many(t, to_mont([pow(w, d - 1, R_MOD), rp, rp * w % R_MOD]))
+        vs = from_mont(vs)
+        p4["t_w_k_minus_1"], p4["t_rp"], p4["t_w_rp"] = vs
+        p4["proof_t_w_k_minus_1"], p4["proof_t_rp"], p4["proof_t_w_rp"] = proofs
+        p4["q_rp"], p4["proof_q_rp"] = self.open(q4, rp)
+        # f = g = T: the reference opens T at w rp twice (prover/part4.rs:63, protocols.rs:663-665)
+        p4["f_w_rp"], p4["proof_f_w_rp"] = self.open(T, rp * w % R_MOD)
+        p4["g_w_rp"], p4["proof_g_w_rp"] = p4["f_w_rp"], p4["proof_f_w_rp"]
+        p4["W_w_rp"], p4["proof_W_w_rp"] = self.open(W, rp * w % R_MOD)
+
+        # part 5 (prover/part5.rs:6-27): the output sits on the last gate's output row
+        out_v, out_proof = self.open(T, pow(w, 3 * ng - 1, R_MOD))
+        if out_v != circuit.output % R_MOD:
+            raise ValueError("Evaluation does not match with output")
+
+        # common/proof.rs:220-266
+        s_ = str
+        hx = self.hex_of
+        return {
+            "pub_inputs": [s_(x % R_MOD) for x in circuit.pub_inputs],
+            "output": s_(circuit.output % R_MOD),
+            "com_T": hx(com_T),
+            "proof_T_minus_v_zero": [hx(p2["com_q"]), s_(p2["f_r"]), hx(p2["proof_f_r"]), s_(p2["q_r"]),
+                                     hx(p2["proof_q_r"])],
+            "proof_T_S_zero": [hx(p3["com_q"]), s_(p3["T_r"]), hx(p3["proof_T_r"]), s_(p3["T_w_r"]),
+                               hx(p3["proof_T_w_r"]), s_(p3["T_w2_r"]), hx(p3["proof_T_w2_r"]), s_(p3["S_r"]),
+                               hx(p3["proof_S_r"]), s_(p3["q_r"]), hx(p3["proof_q_r"])],
+            "proof_T_W_prescribed_permutation": [
+                hx(p4["com_t"]), hx(p4["com_q"]), s_(p4["t_w_k_minus_1"]), hx(p4["proof_t_w_k_minus_1"]),
+                s_(p4["t_rp"]), hx(p4["proof_t_rp"]), s_(p4["t_w_rp"]), hx(p4["proof_t_w_rp"]),
+                s_(p4["q_rp"]), hx(p4["proof_q_rp"]), s_(p4["f_w_rp"]), hx(p4["proof_f_w_rp"]),
+                s_(p4["g_w_rp"]), hx(p4["proof_g_w_rp"]), s_(p4["W_w_rp"]), hx(p4["proof_W_w_rp"])],
+            "proof_last_gate_KZG": hx(out_proof),
+        }

@@ -148,3 +148,42 @@ def test_synthetic_circuit_of_255_gates(backend, monkeypatch):
     want = o.g1_mul(o.G1_GENERATOR, o.poly_eval(T, tau))
     assert proof["com_T"] == o.g1_hex(want)
     assert calls["open"] == 15
+
+
+# ---------------------------------------------------------------------------------------------
+# The host-side prover on limb arrays (plonk_amd/prover.py): no restatement code in the loop.
+# ---------------------------------------------------------------------------------------------
+def test_limb_array_prover_reproduces_the_golden_files(backend, golden):
+    from plonk_amd import prover as pv
+    setup = o.load_setup_json(golden["srs"])
+    backend.srs_load_projective(c.g1_to_limbs(setup.gp.tau_powers_g1))
+    circuit = pv.example_circuit()
+    p = pv.Prover(backend, 12)
+    keys = p.keys(circuit)
+    assert [str(x) for x in pv.from_mont(keys["S"])] == golden["proving_key"]["S"][:len(keys["S"])]
+    assert [int(x) for x in golden["proving_key"]["S"][len(keys["S"]):]] == [0] * (3 - len(keys["S"]))
+    assert [str(x) for x in pv.from_mont(keys["W"])] == golden["proving_key"]["W"]
+    assert p.hex_of(keys["com_S"]) == golden["verification_key"]["com_S"]
+    assert p.hex_of(keys["com_W"]) == golden["verification_key"]["com_W"]
+    assert p.prove(circuit, keys) == golden["proof"]
+
+
+@pytest.mark.parametrize("log_gates", [3, 5])
+def test_limb_array_prover_matches_the_restatement(backend, log_gates):
+    from plonk_amd import prover as pv
+    oc = o.synthetic_circuit(log_gates, 21)
+    d = len(oc.trace)
+    tau = 0xFEDCBA9876543210 + log_gates
+    circuit = pv.Circuit(oc.gates, pv.to_mont(oc.trace), oc.wiring, oc.pub_inputs, oc.output)
+    same = pv.synthetic_circuit(log_gates, 21)
+    assert np.array_equal(same.trace, circuit.trace) and np.array_equal(same.wiring, circuit.wiring)
+    p = pv.Prover(backend, d)
+    p.setup(tau)
+    keys = p.keys(circuit)
+    proof = p.prove(circuit, keys)
+    setup = o.Setup(len(oc.gates), 2, 1, d, o.kzg_setup_with_tau(2 * d - 3, tau))
+    pk, vk = o.reproduce_proving_key(setup, oc), o.reproduce_verification_key(setup, oc)
+    assert [o.fr_to_string(x) for x in pv.from_mont(keys["S"])] == pk["S"]
+    assert [o.fr_to_string(x) for x in pv.from_mont(keys["W"])] == pk["W"]
+    assert {"com_S": p.hex_of(keys["com_S"]), "com_W": p.hex_of(keys["com_W"])} == vk
+    assert proof == o.reproduce_proof(setup, pk, vk, oc)
