@@ -131,6 +131,8 @@ class Prover:
         self.zero = np.zeros(4, dtype=np.uint64)
         # Omega as limbs: the powers of w (f(wX) of the all-ones polynomial)
         self.omega = backend.compose_with_scaling(np.tile(self.one, (d, 1)), _m(self.w))
+        self.kzg_log = None  # set to [] to record every commitment and opening of the next prove()
+        self.challenges = {}
 
     # -- helpers -----------------------------------------------------------------------------
     def setup(self, tau):
@@ -182,7 +184,85 @@ class Prover:
 
     def open(self, poly, point):
         v, proof = self.be.kzg_evaluate(poly, _m(point))
-        return from_mont(v)[0], proof
+        v = from_mont(v)[0]
+        self._log(poly, proof, point, v)
+        return v, proof
+
+    def open_many(self, poly, points):
+        vs, proofs = self.be.kzg_evaluate_many(poly, to_mont(points))
+        vs = from_mont(vs)
+        for point, v, proof in zip(points, vs, proofs):
+            self._log(poly, proof, point, v)
+        return vs, proofs
+
+    def commit(self, *polys):
+        coms = self.be.kzg_commit_batch(list(polys))
+        for poly, com in zip(polys, coms):
+            self._log(poly, com)
+        return coms
+
+    def _log(self, poly, point_g1, u=None, v=None):
+        if self.kzg_log is not None:
+            self.kzg_log.append((poly, np.array(point_g1), u, v))
+
+    def audit_with_tau(self, tau):
+        """With the trapdoor of a test SRS every logged group element can be checked without
+        pairings: a commitment must be [f(tau)]G (plonk/tests/kzg_tests.rs:36-69) and an opening
+        proof [(f(tau) - v) / (tau - u)]G (:95-146).  Returns the number of items checked."""
+        for poly, point, u, v in self.kzg_log:
+            f_tau = from_mont(self.be.fr_eval(poly, _m(tau)))[0]
+            scalar = f_tau if u is None else (f_tau - v) * pow(tau - u, -1, R_MOD) % R_MOD
+            want = self.be.kzg_commit(to_mont([scalar]))  # [scalar]G: the SRS starts with G
+            if self.hex_of(want) != self.hex_of(point):
+                raise AssertionError("commitment or opening proof does not match the trapdoor evaluation")
+        return len(self.kzg_log)
+
+    def check_identities(self, circuit_shape, proof, keys):
+        """The field equations of the verifier (verify_zero_on_roots_test protocols.rs:220-229,
+        verify_T_S_zero_test :789-803, verify_prescribed_permutation_check :702-705) on the opened
+        values of a proof, with the challenges re-derived from its commitments.  circuit_shape:
+        (number_gates, pub_inputs).  The pairing checks are not part of this."""
+        ng, pub_inputs = circuit_shape
+        d, w = self.d, self.w
+        P = R_MOD
+        # part 2
+        rows_in = [pow(w, d - 1 - i, P) for i in range(len(pub_inputs))]
+        v = trim(self.be.interpolate_polynomial(to_mont(rows_in), to_mont(pub_inputs)))
+        com_T = self.be.g1_decompress([bytes.fromhex(proof["com_T"])], check_subgroup=True)[0]
+        com_T_minus_v = self._subtract_points(com_T, self.be.kzg_commit(v))
+        r2 = self.challenge([com_T_minus_v])
+        _, f_r, _, q_r, _ = proof["proof_T_minus_v_zero"]
+        z = 1
+        for x in rows_in:
+            z = z * (r2 - x) % P
+        ok = int(f_r) % P == int(q_r) * z % P
+        # part 3
+        h = hashlib.blake2s()
+        h.update(bytes.fromhex(proof["com_T"]))
+        h.update(bytes.fromhex(self.hex_of(keys["com_S"])))
+        r3 = int.from_bytes(h.digest(), "little") % P
+        _, T_r, _, T_w_r, _, T_w2_r, _, S_r, _, q3_r, _ = proof["proof_T_S_zero"]
+        T_r, T_w_r, T_w2_r, S_r, q3_r = (int(x) for x in (T_r, T_w_r, T_w2_r, S_r, q3_r))
+        n = ng + 1
+        if d == 3 * n:  # the gate rows are the subgroup of order n without its last element
+            z = (pow(r3, n, P) - 1) * pow(r3 - pow(w, 3 * ng, P), -1, P) % P
+        else:
+            z = 1
+            for l in range(ng):
+                z = z * (r3 - pow(w, 3 * l, P)) % P
+        ok = ok and (S_r * (T_r + T_w_r) + (1 - S_r) * T_r * T_w_r - T_w2_r) % P == q3_r * z % P
+        # part 4
+        h = hashlib.blake2s()
+        h.update(bytes.fromhex(proof["com_T"]))
+        h.update(bytes.fromhex(self.hex_of(keys["com_W"])))
+        base = h.digest()
+        r, s_, rp = (int.from_bytes(hashlib.blake2s(base + bytes([i])).digest(), "little") % P for i in range(3))
+        pp = proof["proof_T_W_prescribed_permutation"]
+        t_last, t_rp, t_w_rp, q_rp, f_w_rp, g_w_rp, W_w_rp = (int(pp[i]) for i in (2, 4, 6, 8, 10, 12, 14))
+        ok = ok and t_last == 1
+        ok = ok and (t_w_rp * (r - s_ * w * rp - g_w_rp) - t_rp * (r - s_ * W_w_rp - f_w_rp)) % P == \
+            q_rp * (pow(rp, d, P) - 1) % P
+        return ok
 
     def _subtract_points(self, p, q):
         """p - q for two Jacobian points in limb form (`com_T - com_v`, prover/part2.rs:49)."""
@@ -232,7 +312,17 @@ class Prover:
         return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
 
     # -- prover::run ---------------------------------------------------------------------------
-    def prove(self, circuit, keys):
+    def prove(self, circuit, keys, times=None):
+        """times: optional dict that receives the wall time of each part in seconds."""
+        import time
+        clock = [time.perf_counter()]
+
+        def lap(name):
+            if times is not None:
+                now = time.perf_counter()
+                times[name] = now - clock[0]
+                clock[0] = now
+
         be, d, w = self.be, self.d, self.w
         ng = circuit.number_gates
         S, W = keys["S"], keys["W"]
@@ -240,20 +330,22 @@ class Prover:
         T = self.interpolate_over_omega(circuit.trace)
         if T.shape[0] != d:
             raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
-        com_T = be.kzg_commit(T)
+        com_T = self.commit(T)[0]
+        lap("part1")
 
         # part 2 (prover/part2.rs:14-61): T - v vanishes on the public-input rows
         n_in = len(circuit.pub_inputs)
         rows_in = [pow(w, d - 1 - i, R_MOD) for i in range(n_in)]
         v = trim(be.interpolate_polynomial(to_mont(rows_in), to_mont(circuit.pub_inputs)))
         T_minus_v = trim(self.lin(T, v, 1, -1))
-        com_v = be.kzg_commit(v)
+        com_v = self.commit(v)[0]
         com_T_minus_v = self._subtract_points(com_T, com_v)
         q2 = trim(be.compute_q_zero_test_from_roots(to_mont(rows_in), T_minus_v))
         r2 = self.challenge([com_T_minus_v])
-        p2 = {"com_q": be.kzg_commit(q2)}
+        p2 = {"com_q": self.commit(q2)[0]}
         p2["f_r"], p2["proof_f_r"] = self.open(T_minus_v, r2)
         p2["q_r"], p2["proof_q_r"] = self.open(q2, r2)
+        lap("part2")
 
         # part 3 (prover/part3.rs:16-75, protocols.rs:722-786): the gate constraint
         T_w = self.shift(T, w)
@@ -265,16 +357,17 @@ class Prover:
         rows_gates = self.omega[0:3 * ng:3]
         q3 = trim(be.compute_q_zero_test_from_roots(rows_gates, S_T))
         r3 = self.challenge([com_T, keys["com_S"]])
-        p3 = {"com_q": be.kzg_commit(q3)}
-        vs, proofs = be.kzg_evaluate_many(T, to_mont([r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD]))
-        vs = from_mont(vs)
+        p3 = {"com_q": self.commit(q3)[0]}
+        vs, proofs = self.open_many(T, [r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD])
         p3["T_r"], p3["T_w_r"], p3["T_w2_r"] = vs
         p3["proof_T_r"], p3["proof_T_w_r"], p3["proof_T_w2_r"] = proofs
         p3["S_r"], p3["proof_S_r"] = self.open(S, r3)
         p3["q_r"], p3["proof_q_r"] = self.open(q3, r3)
+        lap("part3")
 
         # part 4 (prover/part4.rs:17-66, protocols.rs:559-687): the wiring, T(W(y)) = T(y) on Omega
         r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
+        self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
         T_vals = self.evaluate_over_omega(T)
         W_vals = self.evaluate_over_omega(W)
         num = self.lin(W_vals, T_vals, -s, -1, r, broadcast=True)   # r - s W(x) - f(x)
@@ -288,10 +381,9 @@ class Prover:
         t1 = trim(self.lin(self.mul(t_w, left), self.mul(t, right), 1, -1))
         q4 = trim(be.compute_q_zero_test(d, t1))
         p4 = {}
-        com = be.kzg_commit_batch([t, q4])
+        com = self.commit(t, q4)
         p4["com_t"], p4["com_q"] = com[0], com[1]
-        vs, proofs = be.kzg_evaluate_many(t, to_mont([pow(w, d - 1, R_MOD), rp, rp * w % R_MOD]))
-        vs = from_mont(vs)
+        vs, proofs = self.open_many(t, [pow(w, d - 1, R_MOD), rp, rp * w % R_MOD])
         p4["t_w_k_minus_1"], p4["t_rp"], p4["t_w_rp"] = vs
         p4["proof_t_w_k_minus_1"], p4["proof_t_rp"], p4["proof_t_w_rp"] = proofs
         p4["q_rp"], p4["proof_q_rp"] = self.open(q4, rp)
@@ -299,11 +391,13 @@ class Prover:
         p4["f_w_rp"], p4["proof_f_w_rp"] = self.open(T, rp * w % R_MOD)
         p4["g_w_rp"], p4["proof_g_w_rp"] = p4["f_w_rp"], p4["proof_f_w_rp"]
         p4["W_w_rp"], p4["proof_W_w_rp"] = self.open(W, rp * w % R_MOD)
+        lap("part4")
 
         # part 5 (prover/part5.rs:6-27): the output sits on the last gate's output row
         out_v, out_proof = self.open(T, pow(w, 3 * ng - 1, R_MOD))
         if out_v != circuit.output % R_MOD:
             raise ValueError("Evaluation does not match with output")
+        lap("part5")
 
         # common/proof.rs:220-266
         s_ = str

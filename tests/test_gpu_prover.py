@@ -180,7 +180,16 @@ def test_limb_array_prover_matches_the_restatement(backend, log_gates):
     p = pv.Prover(backend, d)
     p.setup(tau)
     keys = p.keys(circuit)
+    p.kzg_log = []
     proof = p.prove(circuit, keys)
+    # every commitment and opening against the trapdoor, and the verifier's field equations
+    assert p.audit_with_tau(tau) == 6 + 14  # T is opened at w rp once for f and g
+    shape = (circuit.number_gates, circuit.pub_inputs)
+    assert p.check_identities(shape, proof, keys)
+    forged = dict(proof)
+    forged["proof_T_S_zero"] = list(proof["proof_T_S_zero"])
+    forged["proof_T_S_zero"][1] = str((int(proof["proof_T_S_zero"][1]) + 1) % pv.R_MOD)
+    assert not p.check_identities(shape, forged, keys)
     setup = o.Setup(len(oc.gates), 2, 1, d, o.kzg_setup_with_tau(2 * d - 3, tau))
     pk, vk = o.reproduce_proving_key(setup, oc), o.reproduce_verification_key(setup, oc)
     assert [o.fr_to_string(x) for x in pv.from_mont(keys["S"])] == pk["S"]
