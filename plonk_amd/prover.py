@@ -41,9 +41,16 @@ def _m(value):
 
 
 def trim(poly):
-    """Drops trailing zero coefficients (ark's DensePolynomial invariant)."""
-    nz = np.flatnonzero(poly.any(axis=1))
-    return poly[: (int(nz[-1]) + 1 if nz.size else 0)]
+    """Drops trailing zero coefficients (ark's DensePolynomial invariant).  Scans from the top: the
+    leading coefficient is almost always there already."""
+    n = poly.shape[0]
+    while n:
+        lo = max(0, n - 4096)
+        nz = np.flatnonzero(poly[lo:n].any(axis=1))
+        if nz.size:
+            return poly[: lo + int(nz[-1]) + 1]
+        n = lo
+    return poly[:0]
 
 
 def root_of_unity(n):
