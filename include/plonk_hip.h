@@ -287,6 +287,39 @@ int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, c
  * polynomials.rs:42). */
 int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *coeffs);
 
+/* ---- Device-resident variants ------------------------------------------------------------------
+ * The polynomial entry points above copy their operands from and to host memory on every call, which
+ * is what a caller holding `DensePolynomial`s needs; a prover that keeps its polynomials on the GPU
+ * between the steps of prover/part1-5.rs uses these instead.  Pointers named d_* are device memory
+ * from plonk_hip_malloc; scalars (points, factors) and results that the transcript needs (opened
+ * values, commitments) stay on the host.  Same arithmetic, same error codes as the host forms. */
+int plonk_hip_memcpy_d2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int plonk_hip_memset_zero(plonk_hip_ctx *ctx, void *dst_dev, size_t bytes);
+/* `kzg_evaluate(gp, f, u)` (kzg.rs:63-88) for m points u of one resident polynomial: vs = m x 4,
+ * proofs = m x 18 (host); m <= 64. */
+int plonk_hip_kzg_open_many_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, const uint64_t *us, size_t m,
+                                uint64_t *vs, uint64_t *proofs);
+/* `kzg_commit` (kzg.rs:48-60) of `batch` resident polynomials, commitments to the host (batch x 18);
+ * batch <= 64. */
+int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns, size_t batch,
+                                  uint64_t *outs);
+/* f(wX) in place (`compose_polynomials(f, [0, w])`, polynomials.rs:80-113). */
+int plonk_hip_fr_scale_by_powers_dev(plonk_hip_ctx *ctx, void *d_coeffs, size_t n, const uint64_t w[4]);
+/* `&a * &b`: d_out receives na + nb - 1 coefficients and must not overlap a or b. */
+int plonk_hip_fr_poly_mul_dev(plonk_hip_ctx *ctx, const void *d_a, size_t na, const void *d_b, size_t nb, void *d_out);
+/* plonk_hip_fr_linear_combination on resident vectors; d_out (max(nx, ny) elements) may be d_x or d_y. */
+int plonk_hip_fr_linear_combination_dev(plonk_hip_ctx *ctx, const void *d_x, size_t nx, const void *d_y, size_t ny,
+                                        const uint64_t a[4], const uint64_t b[4], const uint64_t c[4], int broadcast,
+                                        void *d_out);
+/* `compute_q_zero_test_from_roots` (protocols.rs:169-181): d_q receives n - m coefficients, no overlap. */
+int plonk_hip_fr_div_by_roots_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, const void *d_roots, size_t m,
+                                  void *d_q);
+/* `compute_q_zero_test` (protocols.rs:157-166): quotient by X^k - 1, n - k coefficients, no overlap. */
+int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, size_t k, void *d_q);
+/* d_num[i] <- prod_{j<=i} d_num[j] / d_den[j] (protocols.rs:345-353, 571-588); d_den is overwritten with
+ * the inverses.  PLONK_HIP_ERR_ZERO_DENOMINATOR like the host form. */
+int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,6 +370,52 @@ class Backend:
             _u64(out) if n else None))
         return out
 
+    # ------------------------------------------------------------------ device-resident polynomials
+    def memcpy_d2d(self, dst, src, nbytes):
+        self._check(self._lib.plonk_hip_memcpy_d2d(self._ctx, dst, src, nbytes))
+
+    def memset_zero(self, dst, nbytes):
+        self._check(self._lib.plonk_hip_memset_zero(self._ctx, dst, nbytes))
+
+    def kzg_open_many_dev(self, d_coeffs, n, us):
+        us = _fr(us)
+        vs = np.empty((us.shape[0], 4), dtype=np.uint64)
+        proofs = np.empty((us.shape[0], 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_open_many_dev(self._ctx, d_coeffs, n, _u64(us), us.shape[0], _u64(vs),
+                                                          _u64(proofs)))
+        return vs, proofs
+
+    def kzg_commit_many_dev(self, polys):
+        """polys: list of (device pointer, length) -> (len(polys), 18) commitments on the host."""
+        ptrs = (ctypes.c_void_p * len(polys))(*[p for p, _ in polys])
+        ns = (ctypes.c_size_t * len(polys))(*[n for _, n in polys])
+        outs = np.empty((len(polys), 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_commit_many_dev(self._ctx, ptrs, ns, len(polys), _u64(outs)))
+        return outs
+
+    def fr_scale_by_powers_dev(self, d_coeffs, n, w):
+        self._check(self._lib.plonk_hip_fr_scale_by_powers_dev(self._ctx, d_coeffs, n, _u64(_fr(w).reshape(4))))
+
+    def fr_poly_mul_dev(self, d_a, na, d_b, nb, d_out):
+        self._check(self._lib.plonk_hip_fr_poly_mul_dev(self._ctx, d_a, na, d_b, nb, d_out))
+
+    def fr_linear_combination_dev(self, d_x, nx, d_y, ny, a, b, c, broadcast, d_out):
+        self._check(self._lib.plonk_hip_fr_linear_combination_dev(
+            self._ctx, d_x, nx, d_y, ny, _u64(_fr(a).reshape(4)), _u64(_fr(b).reshape(4)), _u64(_fr(c).reshape(4)),
+            1 if broadcast else 0, d_out))
+
+    def fr_div_by_roots_dev(self, d_f, n, d_roots, m, d_q):
+        self._check(self._lib.plonk_hip_fr_div_by_roots_dev(self._ctx, d_f, n, d_roots, m, d_q))
+
+    def fr_div_vanishing_dev(self, d_f, n, k, d_q):
+        self._check(self._lib.plonk_hip_fr_div_vanishing_dev(self._ctx, d_f, n, k, d_q))
+
+    def fr_ratio_prefix_product_dev(self, d_num, d_den, n):
+        self._check(self._lib.plonk_hip_fr_ratio_prefix_product_dev(self._ctx, d_num, d_den, n))
+
+    def fr_ntt_mixed_dev(self, dptr, n, batch=1, inverse=False):
+        self._check(self._lib.plonk_hip_fr_ntt_mixed_dev(self._ctx, dptr, n, batch, 1 if inverse else 0))
+
     def fr_ratio_prefix_product(self, num, den):
         """t_i = prod_{j<=i} num_j / den_j (protocols.rs:345-353, 571-588)."""
         num, den = _fr(num), _fr(den)

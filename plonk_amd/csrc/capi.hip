@@ -722,4 +722,125 @@ int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint6
     return download(ctx, coeffs, d_o, n);
 }
 
+// ---------------------------------------------------------------------------- device-resident variants
+// The same operations on polynomials that already live in device memory (plonk_hip_malloc): nothing
+// crosses PCIe but the scalars.  Stream-ordered like every _dev entry point; the ones that hand
+// back host values wait for them.
+int plonk_hip_memcpy_d2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+    PLONK_ENTER(ctx);
+    if ((!dst_dev || !src_dev) && bytes) return PLONK_HIP_ERR_INVALID_ARG;
+    if (bytes) PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_memset_zero(plonk_hip_ctx *ctx, void *dst_dev, size_t bytes) {
+    PLONK_ENTER(ctx);
+    if (!dst_dev && bytes) return PLONK_HIP_ERR_INVALID_ARG;
+    if (bytes) PLONK_HIP_TRY(ctx, hipMemsetAsync(dst_dev, 0, bytes, ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_open_many_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, const uint64_t *us, size_t m,
+                                uint64_t *vs, uint64_t *proofs) {
+    PLONK_ENTER(ctx);
+    if (!d_coeffs || !us || !vs || !proofs) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
+    if (n - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    if (m > 64) return PLONK_HIP_ERR_INVALID_ARG;
+    const size_t scr = suffix_scan_scratch_elems(n);
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
+    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
+    for (size_t k = 0; k < m; k++) {
+        PLONK_TRY(suffix_scan(ctx, (const Fr *)d_coeffs, n, load_fr(us + 4 * k), d_s, d_s + n));
+        PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, d_out + k));
+        // the next scan overwrites d_s: fetch f(u) first (stream-ordered, the wait comes at the end)
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * k, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs, d_out, m * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns, size_t batch,
+                                  uint64_t *outs) {
+    PLONK_ENTER(ctx);
+    if (!d_coeffs || !ns || !outs || batch > 64) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    for (size_t b = 0; b < batch; b++) {
+        if (!d_coeffs[b]) return PLONK_HIP_ERR_INVALID_ARG;
+        if (ns[b] == 0) return PLONK_HIP_ERR_EMPTY_POLY;
+        if (ns[b] > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    }
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
+    for (size_t b = 0; b < batch; b++) PLONK_TRY(msm_run_dev(ctx, (const Fr *)d_coeffs[b], ns[b], d_out + b));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_fr_scale_by_powers_dev(plonk_hip_ctx *ctx, void *d_coeffs, size_t n, const uint64_t w[4]) {
+    PLONK_ENTER(ctx);
+    if ((!d_coeffs && n) || !w) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    return scale_by_powers(ctx, (Fr *)d_coeffs, n, 1, load_fr(w));
+}
+
+int plonk_hip_fr_poly_mul_dev(plonk_hip_ctx *ctx, const void *d_a, size_t na, const void *d_b, size_t nb, void *d_out) {
+    PLONK_ENTER(ctx);
+    if ((!d_a && na) || (!d_b && nb)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (na == 0 || nb == 0) return PLONK_HIP_OK;
+    if (!d_out) return PLONK_HIP_ERR_INVALID_ARG;
+    return poly_mul_dev(ctx, (const Fr *)d_a, na, (const Fr *)d_b, nb, (Fr *)d_out, na + nb - 1);
+}
+
+int plonk_hip_fr_linear_combination_dev(plonk_hip_ctx *ctx, const void *d_x, size_t nx, const void *d_y, size_t ny,
+                                        const uint64_t a[4], const uint64_t b[4], const uint64_t c[4], int broadcast,
+                                        void *d_out) {
+    PLONK_ENTER(ctx);
+    const size_t n = nx > ny ? nx : ny;
+    if (!a || !b || !c || (!d_x && nx) || (!d_y && ny) || (!d_out && n)) return PLONK_HIP_ERR_INVALID_ARG;
+    return linear_combination(ctx, (const Fr *)d_x, nx, (const Fr *)d_y, ny, load_fr(a), load_fr(b), load_fr(c),
+                              broadcast != 0, (Fr *)d_out);
+}
+
+int plonk_hip_fr_div_by_roots_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, const void *d_roots, size_t m,
+                                  void *d_q) {
+    PLONK_ENTER(ctx);
+    if ((!d_f && n) || (!d_roots && m)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n <= m) return PLONK_HIP_OK;
+    if (!d_q) return PLONK_HIP_ERR_INVALID_ARG;
+    Fr few[24];
+    if (m <= 24 && m) {  // the few-roots path divides by one linear factor after the other, roots on the host
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(few, d_roots, m * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return div_by_roots_dev(ctx, (const Fr *)d_f, n, (const Fr *)d_roots, few, m, (Fr *)d_q);
+}
+
+int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, size_t k, void *d_q) {
+    PLONK_ENTER(ctx);
+    if (!d_f || k == 0) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n <= k) return PLONK_HIP_OK;
+    if (!d_q) return PLONK_HIP_ERR_INVALID_ARG;
+    return div_vanishing(ctx, (const Fr *)d_f, n, k, (Fr *)d_q);
+}
+
+int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n) {
+    PLONK_ENTER(ctx);
+    if ((!d_num || !d_den) && n) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, prefix_scan_scratch_elems(n) * sizeof(Fr)));
+    PLONK_TRY(batch_inverse(ctx, (Fr *)d_den, n, d_flag));
+    PLONK_TRY(pointwise_mul(ctx, (const Fr *)d_num, (const Fr *)d_den, (Fr *)d_num, n));
+    PLONK_TRY(prefix_scan(ctx, (Fr *)d_num, n, true, (Fr *)ctx->scalars_stage.ptr));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    return flag ? PLONK_HIP_ERR_ZERO_DENOMINATOR : PLONK_HIP_OK;
+}
+
 }  // extern "C"

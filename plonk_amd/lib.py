@@ -91,6 +91,23 @@ SIGNATURES = {
     "plonk_hip_fr_linear_combination": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p, c_u64p, ctypes.c_int,
                        c_u64p]),
+    "plonk_hip_memcpy_d2d": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_hip_memset_zero": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_hip_kzg_open_many_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p]),
+    "plonk_hip_kzg_commit_many_dev": (
+        ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_void_p), c_sizep, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_scale_by_powers_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_poly_mul_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_hip_fr_linear_combination_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, c_u64p, c_u64p,
+                       c_u64p, ctypes.c_int, ctypes.c_void_p]),
+    "plonk_hip_fr_div_by_roots_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_hip_fr_div_vanishing_dev": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_hip_fr_ratio_prefix_product_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_hip_fr_ratio_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_poly_mul": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),

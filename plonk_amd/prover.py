@@ -318,6 +318,182 @@ class Prover:
         com = self.be.kzg_commit_batch([S, W])
         return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
 
+    # -- device-resident polynomials ------------------------------------------------------------
+    class _Pool:
+        """Device buffers of one proof: (pointer, length in field elements) pairs, freed together."""
+
+        def __init__(self, be):
+            self.be, self.ptrs = be, []
+
+        def new(self, n):
+            ptr = self.be.malloc(max(n, 1) * 32)
+            self.ptrs.append(ptr)
+            return (ptr, n)
+
+        def put(self, host):
+            host = np.ascontiguousarray(host, dtype=np.uint64).reshape(-1, 4)
+            buf = self.new(host.shape[0])
+            if host.shape[0]:
+                self.be.to_device(host, buf[0])
+            return buf
+
+        def release(self):
+            self.be.sync()
+            for ptr in self.ptrs:
+                self.be.free(ptr)
+            self.ptrs = []
+
+    def prove_resident(self, circuit, keys, times=None):
+        """`prove` with every polynomial kept in device memory between the steps: the trace, S and W go
+        up once, commitments, opened values and proofs come down; same proof, bit for bit."""
+        import time
+        clock = [time.perf_counter()]
+
+        def lap(name):
+            if times is not None:
+                now = time.perf_counter()
+                times[name] = now - clock[0]
+                clock[0] = now
+
+        be, d, w = self.be, self.d, self.w
+        ng = circuit.number_gates
+        pool = self._Pool(be)
+        pow2 = d & (d - 1) == 0
+
+        def transform(buf, inverse):
+            if pow2:
+                be.fr_ntt_dev(buf[0], d.bit_length() - 1, 1, inverse)
+            else:
+                be.fr_ntt_mixed_dev(buf[0], d, 1, inverse)
+
+        def lin(x, y, a, b, c=0, broadcast=False, out=None):
+            x = x or (None, 0)
+            y = y or (None, 0)
+            out = out or pool.new(max(x[1], y[1]))
+            be.fr_linear_combination_dev(x[0], x[1], y[0], y[1], _m(a), _m(b), _m(c), broadcast, out[0])
+            return out
+
+        def mul(a, b):
+            out = pool.new(a[1] + b[1] - 1)
+            be.fr_poly_mul_dev(a[0], a[1], b[0], b[1], out[0])
+            return out
+
+        def copy_padded(src, n):
+            out = pool.new(n)
+            if n > src[1]:
+                be.memset_zero(out[0], n * 32)
+            be.memcpy_d2d(out[0], src[0], min(n, src[1]) * 32)
+            return out
+
+        def shift(src, factor):
+            out = copy_padded(src, src[1])
+            be.fr_scale_by_powers_dev(out[0], out[1], _m(factor))
+            return out
+
+        def commit(*bufs):
+            coms = be.kzg_commit_many_dev(list(bufs))
+            for buf, com in zip(bufs, coms):
+                self._log(buf, com)
+            return coms
+
+        def open_many(buf, points):
+            vs, proofs = be.kzg_open_many_dev(buf[0], buf[1], to_mont(points))
+            vs = from_mont(vs)
+            for point, v, proof in zip(points, vs, proofs):
+                self._log(buf, proof, point, v)
+            return vs, proofs
+
+        def top_is_zero(buf):
+            return not be.from_device(buf[0] + (buf[1] - 1) * 32, (4,)).any()
+
+        try:
+            S, W = pool.put(keys["S"]), pool.put(keys["W"])
+            # part 1
+            T = pool.put(circuit.trace)
+            transform(T, True)
+            if top_is_zero(T):
+                raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
+            com_T = commit(T)[0]
+            lap("part1")
+
+            # part 2
+            n_in = len(circuit.pub_inputs)
+            rows_in = to_mont([pow(w, d - 1 - i, R_MOD) for i in range(n_in)])
+            v = pool.put(trim(be.interpolate_polynomial(rows_in, to_mont(circuit.pub_inputs))))
+            T_minus_v = lin(T, v, 1, -1)
+            com_v = commit(v)[0]
+            com_T_minus_v = self._subtract_points(com_T, com_v)
+            q2 = pool.new(d - n_in)
+            be.fr_div_by_roots_dev(T_minus_v[0], d, pool.put(rows_in)[0], n_in, q2[0])
+            r2 = self.challenge([com_T_minus_v])
+            p2 = {"com_q": commit(q2)[0]}
+            (p2["f_r"],), (p2["proof_f_r"],) = open_many(T_minus_v, [r2])
+            (p2["q_r"],), (p2["proof_q_r"],) = open_many(q2, [r2])
+            lap("part2")
+
+            # part 3
+            T_w = shift(T, w)
+            T_w2 = shift(T, w * w % R_MOD)
+            one_minus_S = lin(S, None, -1, 0, 1)
+            S_T = lin(mul(S, lin(T, T_w, 1, 1)), mul(one_minus_S, mul(T, T_w)), 1, 1)
+            lin(S_T, T_w2, 1, -1, out=S_T)
+            rows_gates = pool.put(self.omega[0:3 * ng:3])
+            q3 = pool.new(S_T[1] - ng)
+            be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
+            r3 = self.challenge([com_T, keys["com_S"]])
+            p3 = {"com_q": commit(q3)[0]}
+            vs, proofs = open_many(T, [r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD])
+            p3["T_r"], p3["T_w_r"], p3["T_w2_r"] = vs
+            p3["proof_T_r"], p3["proof_T_w_r"], p3["proof_T_w2_r"] = proofs
+            (p3["S_r"],), (p3["proof_S_r"],) = open_many(S, [r3])
+            (p3["q_r"],), (p3["proof_q_r"],) = open_many(q3, [r3])
+            lap("part3")
+
+            # part 4
+            r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
+            self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
+            T_vals = copy_padded(T, d)
+            transform(T_vals, False)
+            W_vals = copy_padded(W, d)
+            transform(W_vals, False)
+            omega = pool.put(self.omega)
+            num = lin(W_vals, T_vals, -s, -1, r, broadcast=True)
+            den = lin(omega, T_vals, -s, -1, r, broadcast=True)
+            be.fr_ratio_prefix_product_dev(num[0], den[0], d)
+            t = num
+            transform(t, True)
+            if top_is_zero(t):
+                raise NotImplementedError("extra random interpolation points (protocols.rs:589-600) are not drawn here")
+            t_w = shift(t, w)
+            left = lin(pool.put(to_mont([r, (-s * w) % R_MOD])), T_w, 1, -1)
+            right = lin(shift(W, w), T_w, -s, -1, r)
+            t1 = mul(t_w, left)
+            lin(t1, mul(t, right), 1, -1, out=t1)
+            q4 = pool.new(t1[1] - d)
+            be.fr_div_vanishing_dev(t1[0], t1[1], d, q4[0])
+            p4 = {}
+            com = commit(t, q4)
+            p4["com_t"], p4["com_q"] = com[0], com[1]
+            vs, proofs = open_many(t, [pow(w, d - 1, R_MOD), rp, rp * w % R_MOD])
+            p4["t_w_k_minus_1"], p4["t_rp"], p4["t_w_rp"] = vs
+            p4["proof_t_w_k_minus_1"], p4["proof_t_rp"], p4["proof_t_w_rp"] = proofs
+            (p4["q_rp"],), (p4["proof_q_rp"],) = open_many(q4, [rp])
+            (p4["f_w_rp"],), (p4["proof_f_w_rp"],) = open_many(T, [rp * w % R_MOD])
+            p4["g_w_rp"], p4["proof_g_w_rp"] = p4["f_w_rp"], p4["proof_f_w_rp"]
+            (p4["W_w_rp"],), (p4["proof_W_w_rp"],) = open_many(W, [rp * w % R_MOD])
+            lap("part4")
+
+            # part 5
+            (out_v,), (out_proof,) = open_many(T, [pow(w, 3 * ng - 1, R_MOD)])
+            if out_v != circuit.output % R_MOD:
+                raise ValueError("Evaluation does not match with output")
+            lap("part5")
+            if self.kzg_log is not None:  # the audit reads the polynomials after the buffers are gone
+                self.kzg_log = [(be.from_device(buf[0], (buf[1], 4)), g, u, v) for buf, g, u, v in self.kzg_log]
+        finally:
+            pool.release()
+        return self._proof_json(circuit, com_T, p2, p3, p4, out_proof)
+
     # -- prover::run ---------------------------------------------------------------------------
     def prove(self, circuit, keys, times=None):
         """times: optional dict that receives the wall time of each part in seconds."""
@@ -406,7 +582,10 @@ class Prover:
             raise ValueError("Evaluation does not match with output")
         lap("part5")
 
-        # common/proof.rs:220-266
+        return self._proof_json(circuit, com_T, p2, p3, p4, out_proof)
+
+    def _proof_json(self, circuit, com_T, p2, p3, p4, out_proof):
+        """Field order of common/proof.rs:220-266."""
         s_ = str
         hx = self.hex_of
         return {

@@ -31,11 +31,19 @@ for rep in range(reps):
     proof = p.prove(circuit, keys, times)
     total = time.perf_counter() - t
     print("prove %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in times.items()), flush=True)
+host_proof = proof
+for rep in range(reps):
+    times = {}
+    t = time.perf_counter()
+    proof = p.prove_resident(circuit, keys, times)
+    total = time.perf_counter() - t
+    print("prove_resident %.3f s  " % total + "  ".join("%s %.3f" % kv for kv in times.items()), flush=True)
+print("same proof as the host-buffer path:", proof == host_proof, flush=True)
 print("com_T", proof["com_T"][:32], "output", proof["output"][:24], flush=True)
 # one more proof with every commitment and opening recorded, checked against the trapdoor of this
 # test SRS; then the verifier's field equations on the opened values
 p.kzg_log = []
-proof = p.prove(circuit, keys)
+proof = p.prove_resident(circuit, keys)
 t = time.perf_counter()
 items = p.audit_with_tau(0x123456789ABCDEF0123)
 ok = p.check_identities((circuit.number_gates, circuit.pub_inputs), proof, keys)

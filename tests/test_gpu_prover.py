@@ -166,6 +166,7 @@ def test_limb_array_prover_reproduces_the_golden_files(backend, golden):
     assert p.hex_of(keys["com_S"]) == golden["verification_key"]["com_S"]
     assert p.hex_of(keys["com_W"]) == golden["verification_key"]["com_W"]
     assert p.prove(circuit, keys) == golden["proof"]
+    assert p.prove_resident(circuit, keys) == golden["proof"]  # polynomials kept on the device
 
 
 @pytest.mark.parametrize("log_gates", [3, 5])
@@ -196,3 +197,7 @@ def test_limb_array_prover_matches_the_restatement(backend, log_gates):
     assert [o.fr_to_string(x) for x in pv.from_mont(keys["W"])] == pk["W"]
     assert {"com_S": p.hex_of(keys["com_S"]), "com_W": p.hex_of(keys["com_W"])} == vk
     assert proof == o.reproduce_proof(setup, pk, vk, oc)
+    # the device-resident pipeline: the same proof, the same audit
+    p.kzg_log = []
+    assert p.prove_resident(circuit, keys) == proof
+    assert p.audit_with_tau(tau) == 20
