@@ -1,0 +1,45 @@
+"""Host-only parts of plonk_amd/prover.py (no GPU): limb conversions, trimming, the circuit generators
+against the restatement's, the example's literals."""
+import numpy as np
+import pytest
+
+from oracle import capi as c
+from oracle import pyref as o
+from plonk_amd import prover as pv
+
+
+def test_montgomery_conversions_match_the_oracle():
+    vals = [0, 1, 2, o.R - 1, o.R, o.R + 5, 0x123456789ABCDEF << 100]
+    limbs = pv.to_mont(vals)
+    assert np.array_equal(limbs, c.fr_to_mont([v % o.R for v in vals]))
+    assert pv.from_mont(limbs) == [v % o.R for v in vals]
+    assert pv.from_mont(limbs[3]) == [o.R - 1]
+
+
+def test_trim_drops_only_trailing_zeros():
+    a = pv.to_mont([0, 5, 0, 7, 0, 0])
+    assert pv.trim(a).shape[0] == 4 and pv.trim(a[:1]).shape[0] == 0 and pv.trim(a[:0]).shape[0] == 0
+    big = np.zeros((10000, 4), dtype=np.uint64)
+    assert pv.trim(big).shape[0] == 0
+    big[17] = pv.to_mont([3])[0]
+    assert pv.trim(big).shape[0] == 18
+
+
+def test_root_of_unity_is_construct_omega():
+    for n in (2, 12, 24, 1 << 10, 3 << 20):
+        assert pv.root_of_unity(n) == pow(o.FR_GENERATOR, (o.R - 1) // n, o.R)
+    assert pv.root_of_unity(12) == o.construct_Omega(12)[1]
+    with pytest.raises(ValueError):
+        pv.root_of_unity(7)
+
+
+def test_circuit_generators_match_the_restatement():
+    ex, oex = pv.example_circuit(), o.example_circuit()
+    assert pv.from_mont(ex.trace) == oex.trace and list(ex.wiring) == oex.wiring and list(ex.gates) == oex.gates
+    assert (ex.pub_inputs, ex.output, ex.d, ex.number_gates) == ([5, 6], 77, 12, 3)
+    for k in (2, 3, 6):
+        a, b = pv.synthetic_circuit(k, 33), o.synthetic_circuit(k, 33)
+        assert pv.from_mont(a.trace) == b.trace and list(a.wiring) == b.wiring and list(a.gates) == b.gates
+        assert a.pub_inputs == b.pub_inputs and a.output == b.output and a.d == 3 << k
+    with pytest.raises(ValueError):
+        pv.Circuit([1] * 5, pv.to_mont([1] * 12), list(range(12)), [1, 2], 3)
