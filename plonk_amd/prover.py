@@ -176,8 +176,8 @@ class Prover:
         """common/utils.rs:65-82 (one challenge) and :85-117 (several): Blake2s-256 over the compressed
         commitments, digests read little-endian mod r."""
         h = hashlib.blake2s()
-        for p in points:
-            h.update(bytes(self.be.g1_compress(np.asarray(p).reshape(1, 18))[0]))
+        for enc in self.be.g1_compress(np.stack([np.asarray(p, dtype=np.uint64).reshape(18) for p in points])):
+            h.update(bytes(enc))
         if count is None:
             return int.from_bytes(h.digest(), "little") % R_MOD
         base = h.digest()
@@ -585,22 +585,24 @@ class Prover:
         return self._proof_json(circuit, com_T, p2, p3, p4, out_proof)
 
     def _proof_json(self, circuit, com_T, p2, p3, p4, out_proof):
-        """Field order of common/proof.rs:220-266."""
+        """Field order of common/proof.rs:220-266.  All group elements are compressed in one call (one
+        field inversion per point, side by side)."""
         s_ = str
-        hx = self.hex_of
+        points = [com_T, p2["com_q"], p2["proof_f_r"], p2["proof_q_r"],
+                  p3["com_q"], p3["proof_T_r"], p3["proof_T_w_r"], p3["proof_T_w2_r"], p3["proof_S_r"], p3["proof_q_r"],
+                  p4["com_t"], p4["com_q"], p4["proof_t_w_k_minus_1"], p4["proof_t_rp"], p4["proof_t_w_rp"],
+                  p4["proof_q_rp"], p4["proof_f_w_rp"], p4["proof_g_w_rp"], p4["proof_W_w_rp"], out_proof]
+        hx = [bytes(e).hex() for e in
+              self.be.g1_compress(np.stack([np.asarray(p, dtype=np.uint64).reshape(18) for p in points]))]
         return {
             "pub_inputs": [s_(x % R_MOD) for x in circuit.pub_inputs],
             "output": s_(circuit.output % R_MOD),
-            "com_T": hx(com_T),
-            "proof_T_minus_v_zero": [hx(p2["com_q"]), s_(p2["f_r"]), hx(p2["proof_f_r"]), s_(p2["q_r"]),
-                                     hx(p2["proof_q_r"])],
-            "proof_T_S_zero": [hx(p3["com_q"]), s_(p3["T_r"]), hx(p3["proof_T_r"]), s_(p3["T_w_r"]),
-                               hx(p3["proof_T_w_r"]), s_(p3["T_w2_r"]), hx(p3["proof_T_w2_r"]), s_(p3["S_r"]),
-                               hx(p3["proof_S_r"]), s_(p3["q_r"]), hx(p3["proof_q_r"])],
+            "com_T": hx[0],
+            "proof_T_minus_v_zero": [hx[1], s_(p2["f_r"]), hx[2], s_(p2["q_r"]), hx[3]],
+            "proof_T_S_zero": [hx[4], s_(p3["T_r"]), hx[5], s_(p3["T_w_r"]), hx[6], s_(p3["T_w2_r"]), hx[7],
+                               s_(p3["S_r"]), hx[8], s_(p3["q_r"]), hx[9]],
             "proof_T_W_prescribed_permutation": [
-                hx(p4["com_t"]), hx(p4["com_q"]), s_(p4["t_w_k_minus_1"]), hx(p4["proof_t_w_k_minus_1"]),
-                s_(p4["t_rp"]), hx(p4["proof_t_rp"]), s_(p4["t_w_rp"]), hx(p4["proof_t_w_rp"]),
-                s_(p4["q_rp"]), hx(p4["proof_q_rp"]), s_(p4["f_w_rp"]), hx(p4["proof_f_w_rp"]),
-                s_(p4["g_w_rp"]), hx(p4["proof_g_w_rp"]), s_(p4["W_w_rp"]), hx(p4["proof_W_w_rp"])],
-            "proof_last_gate_KZG": hx(out_proof),
+                hx[10], hx[11], s_(p4["t_w_k_minus_1"]), hx[12], s_(p4["t_rp"]), hx[13], s_(p4["t_w_rp"]), hx[14],
+                s_(p4["q_rp"]), hx[15], s_(p4["f_w_rp"]), hx[16], s_(p4["g_w_rp"]), hx[17], s_(p4["W_w_rp"]), hx[18]],
+            "proof_last_gate_KZG": hx[19],
         }
