@@ -343,9 +343,12 @@ class Prover:
                 self.be.free(ptr)
             self.ptrs = []
 
-    def prove_resident(self, circuit, keys, times=None):
+    def prove_resident(self, circuit, keys, times=None, ranks=None):
         """`prove` with every polynomial kept in device memory between the steps: the trace, S and W go
-        up once, commitments, opened values and proofs come down; same proof, bit for bit."""
+        up once, commitments, opened values and proofs come down; same proof, bit for bit.
+        ranks: None, or an object with `world`, `rank` and `exchange(rows)` (plonk_amd.sharding.
+        TaskExchange): one process per GPU, every rank builds the polynomials, the 18 independent
+        commitments and openings are dealt out round robin and their results gathered."""
         import time
         clock = [time.perf_counter()]
 
@@ -406,32 +409,30 @@ class Prover:
         def top_is_zero(buf):
             return not be.from_device(buf[0] + (buf[1] - 1) * 32, (4,)).any()
 
+        world, rank = (ranks.world, ranks.rank) if ranks is not None else (1, 0)
         try:
             S, W = pool.put(keys["S"]), pool.put(keys["W"])
-            # part 1
+            # part 1, and the one commitment of part 2 that the transcript needs before anything else
             T = pool.put(circuit.trace)
             transform(T, True)
             if top_is_zero(T):
                 raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
-            com_T = commit(T)[0]
-            lap("part1")
-
-            # part 2
             n_in = len(circuit.pub_inputs)
             rows_in = to_mont([pow(w, d - 1 - i, R_MOD) for i in range(n_in)])
             v = pool.put(trim(be.interpolate_polynomial(rows_in, to_mont(circuit.pub_inputs))))
+            com_T, com_v = commit(T, v)
+            # every challenge depends only on com_T, com_v and the keys (prover/part2.rs:55, part3.rs:69,
+            # part4.rs:48): all other commitments and all openings are independent of each other
+            r2 = self.challenge([self._subtract_points(com_T, com_v)])
+            r3 = self.challenge([com_T, keys["com_S"]])
+            r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
+            self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
+            lap("part1")
+
+            # the polynomials of parts 2, 3 and 4
             T_minus_v = lin(T, v, 1, -1)
-            com_v = commit(v)[0]
-            com_T_minus_v = self._subtract_points(com_T, com_v)
             q2 = pool.new(d - n_in)
             be.fr_div_by_roots_dev(T_minus_v[0], d, pool.put(rows_in)[0], n_in, q2[0])
-            r2 = self.challenge([com_T_minus_v])
-            p2 = {"com_q": commit(q2)[0]}
-            (p2["f_r"],), (p2["proof_f_r"],) = open_many(T_minus_v, [r2])
-            (p2["q_r"],), (p2["proof_q_r"],) = open_many(q2, [r2])
-            lap("part2")
-
-            # part 3
             T_w = shift(T, w)
             T_w2 = shift(T, w * w % R_MOD)
             one_minus_S = lin(S, None, -1, 0, 1)
@@ -440,18 +441,6 @@ class Prover:
             rows_gates = pool.put(self.omega[0:3 * ng:3])
             q3 = pool.new(S_T[1] - ng)
             be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
-            r3 = self.challenge([com_T, keys["com_S"]])
-            p3 = {"com_q": commit(q3)[0]}
-            vs, proofs = open_many(T, [r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD])
-            p3["T_r"], p3["T_w_r"], p3["T_w2_r"] = vs
-            p3["proof_T_r"], p3["proof_T_w_r"], p3["proof_T_w2_r"] = proofs
-            (p3["S_r"],), (p3["proof_S_r"],) = open_many(S, [r3])
-            (p3["q_r"],), (p3["proof_q_r"],) = open_many(q3, [r3])
-            lap("part3")
-
-            # part 4
-            r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
-            self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
             T_vals = copy_padded(T, d)
             transform(T_vals, False)
             W_vals = copy_padded(W, d)
@@ -471,23 +460,42 @@ class Prover:
             lin(t1, mul(t, right), 1, -1, out=t1)
             q4 = pool.new(t1[1] - d)
             be.fr_div_vanishing_dev(t1[0], t1[1], d, q4[0])
-            p4 = {}
-            com = commit(t, q4)
-            p4["com_t"], p4["com_q"] = com[0], com[1]
-            vs, proofs = open_many(t, [pow(w, d - 1, R_MOD), rp, rp * w % R_MOD])
-            p4["t_w_k_minus_1"], p4["t_rp"], p4["t_w_rp"] = vs
-            p4["proof_t_w_k_minus_1"], p4["proof_t_rp"], p4["proof_t_w_rp"] = proofs
-            (p4["q_rp"],), (p4["proof_q_rp"],) = open_many(q4, [rp])
-            (p4["f_w_rp"],), (p4["proof_f_w_rp"],) = open_many(T, [rp * w % R_MOD])
-            p4["g_w_rp"], p4["proof_g_w_rp"] = p4["f_w_rp"], p4["proof_f_w_rp"]
-            (p4["W_w_rp"],), (p4["proof_W_w_rp"],) = open_many(W, [rp * w % R_MOD])
-            lap("part4")
+            be.sync()
+            lap("polynomials")
 
-            # part 5
-            (out_v,), (out_proof,) = open_many(T, [pow(w, 3 * ng - 1, R_MOD)])
-            if out_v != circuit.output % R_MOD:
+            # 4 commitments and 14 openings (T at w rp serves f and g), dealt out to the ranks
+            wr = w * r3 % R_MOD
+            tasks = [(q2, None), (T_minus_v, r2), (q2, r2),
+                     (q3, None), (T, r3), (T, wr), (T, w * wr % R_MOD), (S, r3), (q3, r3),
+                     (t, None), (q4, None), (t, pow(w, d - 1, R_MOD)), (t, rp), (t, rp * w % R_MOD), (q4, rp),
+                     (T, rp * w % R_MOD), (W, rp * w % R_MOD), (T, pow(w, 3 * ng - 1, R_MOD))]
+            rows = np.zeros((len(tasks), 22), dtype=np.uint64)
+            for i, (buf, point) in enumerate(tasks):
+                if i % world != rank:
+                    continue
+                if point is None:
+                    rows[i, :18] = commit(buf)[0]
+                else:
+                    (value,), (proof,) = open_many(buf, [point])
+                    rows[i, :18] = proof
+                    rows[i, 18:] = _m(value)
+            lap("commit_open")
+            if world > 1:
+                rows = ranks.exchange(rows)
+                lap("exchange")
+            g1 = rows[:, :18]
+            val = from_mont(rows[:, 18:])
+            if val[17] != circuit.output % R_MOD:
                 raise ValueError("Evaluation does not match with output")
-            lap("part5")
+            p2 = {"com_q": g1[0], "f_r": val[1], "proof_f_r": g1[1], "q_r": val[2], "proof_q_r": g1[2]}
+            p3 = {"com_q": g1[3], "T_r": val[4], "proof_T_r": g1[4], "T_w_r": val[5], "proof_T_w_r": g1[5],
+                  "T_w2_r": val[6], "proof_T_w2_r": g1[6], "S_r": val[7], "proof_S_r": g1[7], "q_r": val[8],
+                  "proof_q_r": g1[8]}
+            p4 = {"com_t": g1[9], "com_q": g1[10], "t_w_k_minus_1": val[11], "proof_t_w_k_minus_1": g1[11],
+                  "t_rp": val[12], "proof_t_rp": g1[12], "t_w_rp": val[13], "proof_t_w_rp": g1[13],
+                  "q_rp": val[14], "proof_q_rp": g1[14], "f_w_rp": val[15], "proof_f_w_rp": g1[15],
+                  "g_w_rp": val[15], "proof_g_w_rp": g1[15], "W_w_rp": val[16], "proof_W_w_rp": g1[16]}
+            out_proof = g1[17]
             if self.kzg_log is not None:  # the audit reads the polynomials after the buffers are gone
                 self.kzg_log = [(be.from_device(buf[0], (buf[1], 4)), g, u, v) for buf, g, u, v in self.kzg_log]
         finally:

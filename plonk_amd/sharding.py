@@ -100,3 +100,30 @@ def commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathere
     if rank == 0:
         be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
     return total_pt
+
+
+class TaskExchange:
+    """Sharing by polynomial: independent commitments / openings are dealt out to the ranks (task i to
+    rank i mod world) and every rank needs all results.  `exchange(rows)` takes this rank's (tasks, k)
+    uint64 array with the rows of its own tasks filled in and returns the array with every row
+    filled in: an all_gather of the raw arrays (opaque limbs, never a reduction), rows picked by owner."""
+
+    def __init__(self, device=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+
+    def exchange(self, rows):
+        import numpy as np
+        mine = torch.from_numpy(np.ascontiguousarray(rows).view(np.int64))
+        staged = dist.get_backend(self.group) == "gloo" or self.device is None
+        if not staged:
+            mine = mine.to(self.device)
+        everyone = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(everyone.view(-1), mine.contiguous().view(-1), group=self.group)
+        everyone = everyone.cpu().numpy().view(np.uint64)
+        out = np.empty_like(rows)
+        for i in range(rows.shape[0]):
+            out[i] = everyone[i % self.world, i]
+        return out

@@ -65,3 +65,46 @@ def test_two_ranks_both_exchanges(tmp_path, log_n):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, port, log_n, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _prover_worker(rank, world, port, log_gates, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import plonk_amd
+    from plonk_amd import prover as pv
+    from plonk_amd import sharding
+
+    torch.cuda.set_device(0)
+    be = plonk_amd.Backend(device=0)
+    circuit = pv.synthetic_circuit(log_gates, 3)
+    p = pv.Prover(be, circuit.d)
+    tau = 0xABCDEF0123456789
+    p.setup(tau)
+    keys = p.keys(circuit)
+    alone = p.prove_resident(circuit, keys)
+    p.kzg_log = []
+    shared = p.prove_resident(circuit, keys, ranks=sharding.TaskExchange(device=torch.device("cuda", 0)))
+    mine = p.audit_with_tau(tau)  # this rank's share of the 18 commitments and openings, plus T and v
+    ok = shared == alone and p.check_identities((circuit.number_gates, circuit.pub_inputs), shared, keys)
+    counts = [None] * world
+    dist.all_gather_object(counts, (mine, bool(ok)))
+    if rank == 0:
+        total = sum(c for c, _ in counts) - 2 * (world - 1)  # every rank commits to T and v
+        with open(out_path, "w") as fh:
+            fh.write("ok" if all(good for _, good in counts) and total == 20 else "mismatch %r" % (counts,))
+    dist.barrier()
+    dist.destroy_process_group()
+    be.close()
+
+
+@pytest.mark.parametrize("world,log_gates", [(2, 6), (3, 10)])
+def test_proof_shared_by_polynomial_between_ranks(tmp_path, world, log_gates):
+    """The 18 independent commitments and openings of a proof dealt out to the ranks (sharing by
+    polynomial): the gathered proof equals the single-rank proof."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "result.txt"
+    mp.spawn(_prover_worker, args=(world, port, log_gates, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"

@@ -121,3 +121,35 @@ def test_bucket_slices_need_a_power_of_two_split():
     for nb, world in ((16, 3), (16, 8), (12, 4)):
         with pytest.raises(ValueError):
             sharding.bucket_slice(nb, world, 0)
+
+
+def _task_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = sharding.TaskExchange()
+    ntasks = 7
+    full = (np.arange(ntasks * 22, dtype=np.uint64).reshape(ntasks, 22) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1 << 63)
+    rows = np.zeros_like(full)
+    for i in range(ntasks):
+        if i % world == rank:
+            rows[i] = full[i]
+    got = ex.exchange(rows)
+    ok = np.array_equal(got, full)
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            fh.write("ok" if all(flags) else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_task_exchange_returns_every_rank_its_rows(tmp_path, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "result.txt"
+    mp.spawn(_task_worker, args=(world, port, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
