@@ -60,6 +60,18 @@ def root_of_unity(n):
     return pow(FR_GENERATOR, (R_MOD - 1) // n, R_MOD)
 
 
+def deal_tasks(sizes, world):
+    """Owner of each task when tasks of the given sizes (coefficients of the MSM) are dealt to `world`
+    ranks: largest first, each to the rank with the least work so far.  The same on every rank."""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for i in sorted(range(len(sizes)), key=lambda j: (-sizes[j], j)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += sizes[i]
+    return owner
+
+
 # ------------------------------------------------------------------------------ circuit description
 class Circuit:
     """gates[l]: 1 addition, 0 multiplication; trace: (d, 4) limbs, the value on every row of Omega;
@@ -348,7 +360,7 @@ class Prover:
         up once, commitments, opened values and proofs come down; same proof, bit for bit.
         ranks: None, or an object with `world`, `rank` and `exchange(rows)` (plonk_amd.sharding.
         TaskExchange): one process per GPU, every rank builds the polynomials, the 18 independent
-        commitments and openings are dealt out round robin and their results gathered."""
+        commitments and openings are dealt out by size (`deal_tasks`) and their results gathered."""
         import time
         clock = [time.perf_counter()]
 
@@ -470,8 +482,9 @@ class Prover:
                      (t, None), (q4, None), (t, pow(w, d - 1, R_MOD)), (t, rp), (t, rp * w % R_MOD), (q4, rp),
                      (T, rp * w % R_MOD), (W, rp * w % R_MOD), (T, pow(w, 3 * ng - 1, R_MOD))]
             rows = np.zeros((len(tasks), 22), dtype=np.uint64)
+            owner = deal_tasks([buf[1] for buf, _ in tasks], world)
             for i, (buf, point) in enumerate(tasks):
-                if i % world != rank:
+                if owner[i] != rank:
                     continue
                 if point is None:
                     rows[i, :18] = commit(buf)[0]
@@ -481,7 +494,7 @@ class Prover:
                     rows[i, 18:] = _m(value)
             lap("commit_open")
             if world > 1:
-                rows = ranks.exchange(rows)
+                rows = ranks.exchange(rows, owner)
                 lap("exchange")
             g1 = rows[:, :18]
             val = from_mont(rows[:, 18:])

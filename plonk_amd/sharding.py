@@ -103,10 +103,11 @@ def commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathere
 
 
 class TaskExchange:
-    """Sharing by polynomial: independent commitments / openings are dealt out to the ranks (task i to
-    rank i mod world) and every rank needs all results.  `exchange(rows)` takes this rank's (tasks, k)
-    uint64 array with the rows of its own tasks filled in and returns the array with every row
-    filled in: an all_gather of the raw arrays (opaque limbs, never a reduction), rows picked by owner."""
+    """Sharing by polynomial: independent commitments / openings are dealt out to the ranks and every
+    rank needs all results.  `exchange(rows, owner)` takes this rank's (tasks, k) uint64 array with the
+    rows of its own tasks filled in and the owner rank of every task (default: task i to rank
+    i mod world) and returns the array with every row filled in: an all_gather of the raw arrays
+    (opaque limbs, never a reduction), rows picked by owner."""
 
     def __init__(self, device=None, group=None):
         self.group = group
@@ -114,7 +115,7 @@ class TaskExchange:
         self.rank = dist.get_rank(group)
         self.device = device
 
-    def exchange(self, rows):
+    def exchange(self, rows, owner=None):
         import numpy as np
         mine = torch.from_numpy(np.ascontiguousarray(rows).view(np.int64))
         staged = dist.get_backend(self.group) == "gloo" or self.device is None
@@ -125,5 +126,5 @@ class TaskExchange:
         everyone = everyone.cpu().numpy().view(np.uint64)
         out = np.empty_like(rows)
         for i in range(rows.shape[0]):
-            out[i] = everyone[i % self.world, i]
+            out[i] = everyone[owner[i] if owner is not None else i % self.world, i]
         return out

@@ -43,3 +43,12 @@ def test_circuit_generators_match_the_restatement():
         assert a.pub_inputs == b.pub_inputs and a.output == b.output and a.d == 3 << k
     with pytest.raises(ValueError):
         pv.Circuit([1] * 5, pv.to_mont([1] * 12), list(range(12)), [1, 2], 3)
+
+
+def test_tasks_are_dealt_by_size():
+    sizes = [10, 3, 3, 20, 10, 10, 1]
+    assert pv.deal_tasks(sizes, 1) == [0] * 7
+    owner = pv.deal_tasks(sizes, 3)
+    load = [sum(s for s, o_ in zip(sizes, owner) if o_ == r) for r in range(3)]
+    assert sorted(load) == [17, 20, 20] and owner[3] == 0
+    assert pv.deal_tasks(sizes, 3) == owner  # deterministic: every rank computes the same deal
