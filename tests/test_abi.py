@@ -24,3 +24,17 @@ def test_error_strings():
     # same text as the reference's CommitError::CommitFailed (plonk/src/common/kzg.rs:13)
     assert lib.plonk_hip_strerror(-1) == b"Length of tau_powers_g1 must be at least equal to degree of polynomial + 1"
     assert lib.plonk_hip_msm_phase_name(3) == b"accumulate"
+
+
+def test_cpp_wrapper_compiles_as_plain_cpp(tmp_path):
+    """include/plonk_hip.hpp needs nothing but the C header: a caller builds it with g++ alone."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "plonk_hip.hpp"\n'
+                   "int main() { plonk_hip::DensePolynomial f(3); return (int)f.size() - 3; }\n")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                           str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "kzg_roundtrip.cpp")])

@@ -285,3 +285,31 @@ def test_commit_2_26_points_known_answer(backend):
     sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
     got = backend.kzg_commit(sc)
     assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+
+
+def test_compiled_host_program_on_the_cpp_wrapper(backend):
+    """examples/kzg_roundtrip.cpp (built by the Makefile with plain g++ against include/plonk_hip.hpp):
+    setup, commit, open, error behaviour from a compiled caller, checked against the oracle."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(plonk_amd.__file__), "_lib", "kzg_roundtrip")
+    assert os.path.exists(exe), "run make -C plonk_amd/csrc"
+    rnd = random.Random(77)
+    n = 700
+    tau_i, u_i = rnd.randrange(1, o.R), rnd.randrange(o.R)
+    tau, u = c.fr_to_mont([tau_i])[0], c.fr_to_mont([u_i])[0]
+    coeffs = c.fr_to_mont(rand_fr(rnd, n))
+    args = [exe, str(n - 1)] + ["%x" % int(x) for x in tau] + ["%x" % int(x) for x in u]
+    res = subprocess.run(args, input=coeffs.tobytes(), capture_output=True, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()
+    lines = res.stdout.decode().split("\n")
+    assert lines[0] == "srs %d" % n
+    f_tau, v = c.fr_eval(coeffs, tau), c.fr_eval(coeffs, u)
+    assert lines[1] == c.g1_compress(c.g1_mul(c.g1_generator(), f_tau).reshape(1, 18))[0].hex()
+    assert [int(x, 16) for x in lines[2].split()] == [int(x) for x in v]
+    quotient_at_tau = (c.fr_from_mont(f_tau.reshape(1, 4))[0] - c.fr_from_mont(v.reshape(1, 4))[0]) * pow(tau_i - u_i, -1, o.R) % o.R
+    want = c.g1_mul(c.g1_generator(), c.fr_to_mont([quotient_at_tau])[0])
+    assert lines[3] == c.g1_compress(want.reshape(1, 18))[0].hex()
+    assert lines[4] == "roundtrip ok"
+    assert lines[5].startswith("commit_error ") and "MISSING" not in lines[5]
+    assert lines[6] == "panic ok"
