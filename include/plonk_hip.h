@@ -316,6 +316,9 @@ int plonk_hip_fr_div_by_roots_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n,
                                   void *d_q);
 /* `compute_q_zero_test` (protocols.rs:157-166): quotient by X^k - 1, n - k coefficients, no overlap. */
 int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, size_t k, void *d_q);
+/* *is_zero = 1 when all n resident elements are zero (the remainder of an exact division, the values
+ * of a constraint polynomial on its rows: the `assert!`s of prover/part3.rs:61-64, part4.rs:58). */
+int plonk_hip_fr_is_zero_dev(plonk_hip_ctx *ctx, const void *d_x, size_t n, int *is_zero);
 /* d_num[i] <- prod_{j<=i} d_num[j] / d_den[j] (protocols.rs:345-353, 571-588); d_den is overwritten with
  * the inverses.  PLONK_HIP_ERR_ZERO_DENOMINATOR like the host form. */
 int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n);

@@ -410,6 +410,11 @@ class Backend:
     def fr_div_vanishing_dev(self, d_f, n, k, d_q):
         self._check(self._lib.plonk_hip_fr_div_vanishing_dev(self._ctx, d_f, n, k, d_q))
 
+    def fr_is_zero_dev(self, d_x, n):
+        flag = ctypes.c_int(0)
+        self._check(self._lib.plonk_hip_fr_is_zero_dev(self._ctx, d_x, n, ctypes.byref(flag)))
+        return bool(flag.value)
+
     def fr_ratio_prefix_product_dev(self, d_num, d_den, n):
         self._check(self._lib.plonk_hip_fr_ratio_prefix_product_dev(self._ctx, d_num, d_den, n))
 

@@ -829,6 +829,17 @@ int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n
     return div_vanishing(ctx, (const Fr *)d_f, n, k, (Fr *)d_q);
 }
 
+int plonk_hip_fr_is_zero_dev(plonk_hip_ctx *ctx, const void *d_x, size_t n, int *is_zero) {
+    PLONK_ENTER(ctx);
+    if ((!d_x && n) || !is_zero) return PLONK_HIP_ERR_INVALID_ARG;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(any_nonzero(ctx, (const Fr *)d_x, n, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    *is_zero = flag ? 0 : 1;
+    return PLONK_HIP_OK;
+}
+
 int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n) {
     PLONK_ENTER(ctx);
     if ((!d_num || !d_den) && n) return PLONK_HIP_ERR_INVALID_ARG;

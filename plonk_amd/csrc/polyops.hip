@@ -196,6 +196,17 @@ int linear_combination(plonk_hip_ctx *ctx, const Fr *x, size_t nx, const Fr *y, 
     return PLONK_HIP_OK;
 }
 
+// *flag |= 1 when some element is not zero
+__global__ __launch_bounds__(256) void k_any_nonzero(const Fr *__restrict__ x, size_t n, int *__restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !fe_is_zero(x[i])) atomicOr(flag, 1);
+}
+
+int any_nonzero(plonk_hip_ctx *ctx, const Fr *x, size_t n, int *d_flag) {
+    if (n) hipLaunchKernelGGL(k_any_nonzero, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d_flag);
+    return PLONK_HIP_OK;
+}
+
 // out[j] = sum_t f[j + t*k], j < k: the residue of f modulo X^k - 1 (same values on the k-th roots of unity)
 __global__ __launch_bounds__(256) void k_fold(const Fr *__restrict__ f, size_t n, size_t k, Fr *__restrict__ out) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

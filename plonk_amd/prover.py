@@ -330,6 +330,28 @@ class Prover:
         com = self.be.kzg_commit_batch([S, W])
         return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
 
+    def _gate_rows_are_a_subgroup_less_one(self, ng):
+        n = ng + 1
+        return self.d == 3 * n and n & (n - 1) == 0
+
+    def _gate_quotient_host(self, S_T, ng):
+        """S_T / Z_gates (prover/part3.rs:66, protocols.rs:169-181).  When the gate rows Omega[3l] are
+        the subgroup of order n = ng + 1 without its last element rho, Z_gates (X - rho) = X^n - 1 and
+        the quotient is S_T (X - rho) / (X^n - 1): two linear passes instead of a product tree and a
+        series division.  The remainder must vanish, which is the reference's assertion that S_T
+        cancels on every gate row (prover/part3.rs:61-64)."""
+        be = self.be
+        if not self._gate_rows_are_a_subgroup_less_one(ng):
+            return trim(be.compute_q_zero_test_from_roots(self.omega[0:3 * ng:3], S_T))
+        n, rho = ng + 1, pow(self.w, 3 * ng, R_MOD)
+        shifted = np.zeros((S_T.shape[0] + 1, 4), dtype=np.uint64)
+        shifted[1:] = S_T
+        product = self.lin(shifted, S_T, 1, -rho)
+        q = be.compute_q_zero_test(n, product)
+        if self.lin(product[:n], q[:n], 1, 1).any():
+            raise ValueError("S_T should cancel on y (prover/part3.rs:61-64)")
+        return trim(q)
+
     # -- device-resident polynomials ------------------------------------------------------------
     class _Pool:
         """Device buffers of one proof: (pointer, length in field elements) pairs, freed together."""
@@ -450,9 +472,21 @@ class Prover:
             one_minus_S = lin(S, None, -1, 0, 1)
             S_T = lin(mul(S, lin(T, T_w, 1, 1)), mul(one_minus_S, mul(T, T_w)), 1, 1)
             lin(S_T, T_w2, 1, -1, out=S_T)
-            rows_gates = pool.put(self.omega[0:3 * ng:3])
             q3 = pool.new(S_T[1] - ng)
-            be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
+            if self._gate_rows_are_a_subgroup_less_one(ng):
+                # Z_gates (X - rho) = X^n - 1: multiply by the missing factor, divide by X^n - 1
+                n_sub, rho = ng + 1, pow(w, 3 * ng, R_MOD)
+                shifted = pool.new(S_T[1] + 1)
+                be.memset_zero(shifted[0], 32)
+                be.memcpy_d2d(shifted[0] + 32, S_T[0], S_T[1] * 32)
+                lin(shifted, S_T, 1, -rho, out=shifted)
+                be.fr_div_vanishing_dev(shifted[0], shifted[1], n_sub, q3[0])
+                rem = lin((shifted[0], n_sub), (q3[0], min(n_sub, q3[1])), 1, 1)
+                if not be.fr_is_zero_dev(rem[0], rem[1]):
+                    raise ValueError("S_T should cancel on y (prover/part3.rs:61-64)")
+            else:
+                rows_gates = pool.put(self.omega[0:3 * ng:3])
+                be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
             T_vals = copy_padded(T, d)
             transform(T_vals, False)
             W_vals = copy_padded(W, d)
@@ -558,8 +592,7 @@ class Prover:
         S_T = self.lin(self.lin(self.mul(S, self.lin(T, T_w, 1, 1)),
                                 self.mul(one_minus_S, self.mul(T, T_w)), 1, 1), T_w2, 1, -1)
         S_T = trim(S_T)
-        rows_gates = self.omega[0:3 * ng:3]
-        q3 = trim(be.compute_q_zero_test_from_roots(rows_gates, S_T))
+        q3 = self._gate_quotient_host(S_T, ng)
         r3 = self.challenge([com_T, keys["com_S"]])
         p3 = {"com_q": self.commit(q3)[0]}
         vs, proofs = self.open_many(T, [r3, w * r3 % R_MOD, w * w % R_MOD * r3 % R_MOD])
