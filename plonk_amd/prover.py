@@ -330,6 +330,13 @@ class Prover:
         com = self.be.kzg_commit_batch([S, W])
         return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
 
+    @staticmethod
+    def _check_wiring(circuit):
+        """T(W(y)) = T(y) on every row (the assertion of prover/part4.rs:36-42): rows joined by the wiring
+        carry the same value."""
+        if not np.array_equal(circuit.trace[circuit.wiring], circuit.trace):
+            raise ValueError("T_W should be equal to T on Omega (prover/part4.rs:36-42)")
+
     def _gate_rows_are_a_subgroup_less_one(self, ng):
         n = ng + 1
         return self.d == 3 * n and n & (n - 1) == 0
@@ -447,6 +454,7 @@ class Prover:
         try:
             S, W = pool.put(keys["S"]), pool.put(keys["W"])
             # part 1, and the one commitment of part 2 that the transcript needs before anything else
+            self._check_wiring(circuit)
             T = pool.put(circuit.trace)
             transform(T, True)
             if top_is_zero(T):
@@ -506,6 +514,9 @@ class Prover:
             lin(t1, mul(t, right), 1, -1, out=t1)
             q4 = pool.new(t1[1] - d)
             be.fr_div_vanishing_dev(t1[0], t1[1], d, q4[0])
+            rem = lin((t1[0], d), (q4[0], min(d, q4[1])), 1, 1)  # t1 = q4 X^d - q4 + remainder
+            if not be.fr_is_zero_dev(rem[0], rem[1]):
+                raise ValueError("t1 must be divisible by Z_Omega (prover/part4.rs:58)")
             be.sync()
             lap("polynomials")
 
@@ -565,6 +576,7 @@ class Prover:
         ng = circuit.number_gates
         S, W = keys["S"], keys["W"]
         # part 1 (prover/part1.rs:9-69)
+        self._check_wiring(circuit)
         T = self.interpolate_over_omega(circuit.trace)
         if T.shape[0] != d:
             raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
@@ -617,6 +629,8 @@ class Prover:
         right = self.lin(self.shift(W, w), T_w, -s, -1, r)                 # r - s W(wX) - f(wX)
         t1 = trim(self.lin(self.mul(t_w, left), self.mul(t, right), 1, -1))
         q4 = trim(be.compute_q_zero_test(d, t1))
+        if self.lin(t1[:d], q4[:d], 1, 1).any():
+            raise ValueError("t1 must be divisible by Z_Omega (prover/part4.rs:58)")
         p4 = {}
         com = self.commit(t, q4)
         p4["com_t"], p4["com_q"] = com[0], com[1]

@@ -201,3 +201,37 @@ def test_limb_array_prover_matches_the_restatement(backend, log_gates):
     p.kzg_log = []
     assert p.prove_resident(circuit, keys) == proof
     assert p.audit_with_tau(tau) == 20
+
+
+def test_limb_array_prover_rejects_what_the_reference_asserts(backend):
+    """A wrong gate output, a broken wiring and a wrong claimed output stop the prover where the reference's
+    assertions do (prover/part3.rs:61-64, part4.rs:36-42, part5.rs:23-26), on both paths."""
+    from plonk_amd import prover as pv
+    good = pv.synthetic_circuit(4, 9)
+    p = pv.Prover(backend, good.d)
+    p.setup(12345)
+    keys = p.keys(good)
+
+    def variant(**kw):
+        f = dict(gates=good.gates, trace=good.trace.copy(), wiring=good.wiring.copy(), pub_inputs=good.pub_inputs,
+                 output=good.output)
+        f.update(kw)
+        return pv.Circuit(f["gates"], f["trace"], f["wiring"], f["pub_inputs"], f["output"])
+
+    bad_gate = variant()
+    # a gate output used nowhere else: only the gate constraint breaks
+    last_out = 3 * good.number_gates - 1
+    bad_gate.trace[last_out] = pv.to_mont([pv.from_mont(good.trace[last_out])[0] + 1])[0]
+    bad_gate.output = (good.output + 1) % pv.R_MOD
+    bad_wire = variant()
+    j = int(np.flatnonzero(good.wiring != np.arange(good.d))[0])
+    bad_wire.trace[j] = pv.to_mont([7])[0]
+    bad_output = variant(output=(good.output + 1) % pv.R_MOD)
+    for prove in (p.prove, p.prove_resident):
+        with pytest.raises(ValueError, match="S_T should cancel"):
+            prove(bad_gate, keys)
+        with pytest.raises(ValueError, match="T_W should be equal"):
+            prove(bad_wire, keys)
+        with pytest.raises(ValueError, match="does not match with output"):
+            prove(bad_output, keys)
+        assert prove(good, keys)["output"] == str(good.output)
