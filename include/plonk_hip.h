@@ -316,6 +316,10 @@ int plonk_hip_fr_div_by_roots_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n,
                                   void *d_q);
 /* `compute_q_zero_test` (protocols.rs:157-166): quotient by X^k - 1, n - k coefficients, no overlap. */
 int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n, size_t k, void *d_q);
+/* *holds = 1 when values[perm[i]] == values[i] for all i < n: the wiring assertion T(W(y)) = T(y) on
+ * Omega (prover/part4.rs:36-42) on the trace values.  d_values resident, perm (n indices) on the host. */
+int plonk_hip_fr_respects_permutation_dev(plonk_hip_ctx *ctx, const void *d_values, const uint32_t *perm, size_t n,
+                                          int *holds);
 /* *is_zero = 1 when all n resident elements are zero (the remainder of an exact division, the values
  * of a constraint polynomial on its rows: the `assert!`s of prover/part3.rs:61-64, part4.rs:58). */
 int plonk_hip_fr_is_zero_dev(plonk_hip_ctx *ctx, const void *d_x, size_t n, int *is_zero);

@@ -410,6 +410,15 @@ class Backend:
     def fr_div_vanishing_dev(self, d_f, n, k, d_q):
         self._check(self._lib.plonk_hip_fr_div_vanishing_dev(self._ctx, d_f, n, k, d_q))
 
+    def fr_respects_permutation_dev(self, d_values, perm):
+        """values[perm[i]] == values[i] for every i (perm: integer array, on the host)."""
+        perm = np.ascontiguousarray(perm, dtype=np.uint32)
+        flag = ctypes.c_int(0)
+        self._check(self._lib.plonk_hip_fr_respects_permutation_dev(
+            self._ctx, d_values, perm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), perm.shape[0],
+            ctypes.byref(flag)))
+        return bool(flag.value)
+
     def fr_is_zero_dev(self, d_x, n):
         flag = ctypes.c_int(0)
         self._check(self._lib.plonk_hip_fr_is_zero_dev(self._ctx, d_x, n, ctypes.byref(flag)))

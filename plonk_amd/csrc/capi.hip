@@ -829,6 +829,21 @@ int plonk_hip_fr_div_vanishing_dev(plonk_hip_ctx *ctx, const void *d_f, size_t n
     return div_vanishing(ctx, (const Fr *)d_f, n, k, (Fr *)d_q);
 }
 
+int plonk_hip_fr_respects_permutation_dev(plonk_hip_ctx *ctx, const void *d_values, const uint32_t *perm, size_t n,
+                                          int *holds) {
+    PLONK_ENTER(ctx);
+    if (((!d_values || !perm) && n) || !holds || n > 0xffffffffull) return PLONK_HIP_ERR_INVALID_ARG;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, n * sizeof(uint32_t)));
+    uint32_t *d_perm = (uint32_t *)ctx->scratch_c.ptr;
+    if (n) PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_perm, perm, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(permutation_mismatch(ctx, (const Fr *)d_values, d_perm, n, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    *holds = flag ? 0 : 1;
+    return PLONK_HIP_OK;
+}
+
 int plonk_hip_fr_is_zero_dev(plonk_hip_ctx *ctx, const void *d_x, size_t n, int *is_zero) {
     PLONK_ENTER(ctx);
     if ((!d_x && n) || !is_zero) return PLONK_HIP_ERR_INVALID_ARG;

@@ -22,6 +22,8 @@ int pointwise_mul(plonk_hip_ctx *ctx, const Fr *a, const Fr *b, Fr *out, size_t 
 // out[i] = a x[i] + b y[i] + (i == 0 || broadcast ? c : 0), i < max(nx, ny)
 int linear_combination(plonk_hip_ctx *ctx, const Fr *x, size_t nx, const Fr *y, size_t ny, const Fr &a, const Fr &b,
                        const Fr &c, bool broadcast, Fr *out);
+// *d_flag |= 1 when x[perm[i]] != x[i] for some i
+int permutation_mismatch(plonk_hip_ctx *ctx, const Fr *x, const uint32_t *perm, size_t n, int *d_flag);
 // *d_flag |= 1 when some x[i] != 0
 int any_nonzero(plonk_hip_ctx *ctx, const Fr *x, size_t n, int *d_flag);
 // out[j] = sum_t f[j + t*k], j < k

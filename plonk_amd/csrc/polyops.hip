@@ -207,6 +207,20 @@ int any_nonzero(plonk_hip_ctx *ctx, const Fr *x, size_t n, int *d_flag) {
     return PLONK_HIP_OK;
 }
 
+// *flag |= 1 when x[perm[i]] != x[i] for some i (or perm[i] is out of range)
+__global__ __launch_bounds__(256) void k_permutation_mismatch(const Fr *__restrict__ x, const uint32_t *__restrict__ perm,
+                                                             size_t n, int *__restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = perm[i];
+    if (j >= n || !fe_eq(x[j], x[i])) atomicOr(flag, 1);
+}
+
+int permutation_mismatch(plonk_hip_ctx *ctx, const Fr *x, const uint32_t *perm, size_t n, int *d_flag) {
+    if (n) hipLaunchKernelGGL(k_permutation_mismatch, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, x, perm, n, d_flag);
+    return PLONK_HIP_OK;
+}
+
 // out[j] = sum_t f[j + t*k], j < k: the residue of f modulo X^k - 1 (same values on the k-th roots of unity)
 __global__ __launch_bounds__(256) void k_fold(const Fr *__restrict__ f, size_t n, size_t k, Fr *__restrict__ out) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

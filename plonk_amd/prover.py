@@ -80,7 +80,7 @@ class Circuit:
     def __init__(self, gates, trace, wiring, pub_inputs, output):
         self.gates = np.asarray(gates, dtype=np.uint8)
         self.trace = np.ascontiguousarray(trace, dtype=np.uint64).reshape(-1, 4)
-        self.wiring = np.asarray(wiring, dtype=np.int64)
+        self.wiring = np.asarray(wiring, dtype=np.uint32)
         self.pub_inputs = [int(x) for x in pub_inputs]
         self.output = int(output)
         self.d = self.trace.shape[0]
@@ -151,6 +151,7 @@ class Prover:
         # Omega as limbs: the powers of w (f(wX) of the all-ones polynomial)
         self.omega = backend.compose_with_scaling(np.tile(self.one, (d, 1)), _m(self.w))
         self.kzg_log = None  # set to [] to record every commitment and opening of the next prove()
+        self._buffer_cache = {}  # size in bytes -> free device buffers (see _Pool)
         self.challenges = {}
 
     # -- helpers -----------------------------------------------------------------------------
@@ -330,12 +331,15 @@ class Prover:
         com = self.be.kzg_commit_batch([S, W])
         return {"S": S, "W": W, "com_S": com[0], "com_W": com[1]}
 
-    @staticmethod
-    def _check_wiring(circuit):
+    def _check_wiring(self, circuit):
         """T(W(y)) = T(y) on every row (the assertion of prover/part4.rs:36-42): rows joined by the wiring
-        carry the same value."""
-        if not np.array_equal(circuit.trace[circuit.wiring], circuit.trace):
-            raise ValueError("T_W should be equal to T on Omega (prover/part4.rs:36-42)")
+        carry the same value.  Checked on the device (a gather over the trace)."""
+        d_trace = self.be.to_device(circuit.trace)
+        try:
+            if not self.be.fr_respects_permutation_dev(d_trace, circuit.wiring):
+                raise ValueError("T_W should be equal to T on Omega (prover/part4.rs:36-42)")
+        finally:
+            self.be.free(d_trace)
 
     def _gate_rows_are_a_subgroup_less_one(self, ng):
         n = ng + 1
@@ -361,14 +365,18 @@ class Prover:
 
     # -- device-resident polynomials ------------------------------------------------------------
     class _Pool:
-        """Device buffers of one proof: (pointer, length in field elements) pairs, freed together."""
+        """Device buffers of one proof: (pointer, length in field elements) pairs.  Released buffers go
+        back to the prover's cache (by size) instead of the allocator: the next proof of the same circuit
+        size reuses them, and nothing is allocated or freed while a proof runs."""
 
-        def __init__(self, be):
-            self.be, self.ptrs = be, []
+        def __init__(self, be, cache):
+            self.be, self.cache, self.taken = be, cache, []
 
         def new(self, n):
-            ptr = self.be.malloc(max(n, 1) * 32)
-            self.ptrs.append(ptr)
+            nbytes = max(n, 1) * 32
+            free = self.cache.get(nbytes)
+            ptr = free.pop() if free else self.be.malloc(nbytes)
+            self.taken.append((ptr, nbytes))
             return (ptr, n)
 
         def put(self, host):
@@ -380,9 +388,17 @@ class Prover:
 
         def release(self):
             self.be.sync()
-            for ptr in self.ptrs:
+            for ptr, nbytes in self.taken:
+                self.cache.setdefault(nbytes, []).append(ptr)
+            self.taken = []
+
+    def release_buffers(self):
+        """Frees the device buffers kept from earlier proofs."""
+        self.be.sync()
+        for ptrs in self._buffer_cache.values():
+            for ptr in ptrs:
                 self.be.free(ptr)
-            self.ptrs = []
+        self._buffer_cache = {}
 
     def prove_resident(self, circuit, keys, times=None, ranks=None):
         """`prove` with every polynomial kept in device memory between the steps: the trace, S and W go
@@ -401,7 +417,7 @@ class Prover:
 
         be, d, w = self.be, self.d, self.w
         ng = circuit.number_gates
-        pool = self._Pool(be)
+        pool = self._Pool(be, self._buffer_cache)
         pow2 = d & (d - 1) == 0
 
         def transform(buf, inverse):
@@ -454,8 +470,9 @@ class Prover:
         try:
             S, W = pool.put(keys["S"]), pool.put(keys["W"])
             # part 1, and the one commitment of part 2 that the transcript needs before anything else
-            self._check_wiring(circuit)
             T = pool.put(circuit.trace)
+            if not be.fr_respects_permutation_dev(T[0], circuit.wiring):
+                raise ValueError("T_W should be equal to T on Omega (prover/part4.rs:36-42)")
             transform(T, True)
             if top_is_zero(T):
                 raise ValueError("T must have degree d - 1 (prover/part1.rs:63-65)")
