@@ -188,8 +188,13 @@ class Prover:
     def challenge(self, points, count=None):
         """common/utils.rs:65-82 (one challenge) and :85-117 (several): Blake2s-256 over the compressed
         commitments, digests read little-endian mod r."""
+        encodings = self.be.g1_compress(np.stack([np.asarray(p, dtype=np.uint64).reshape(18) for p in points]))
+        return self.challenge_from_encodings(encodings, count)
+
+    @staticmethod
+    def challenge_from_encodings(encodings, count=None):
         h = hashlib.blake2s()
-        for enc in self.be.g1_compress(np.stack([np.asarray(p, dtype=np.uint64).reshape(18) for p in points])):
+        for enc in encodings:
             h.update(bytes(enc))
         if count is None:
             return int.from_bytes(h.digest(), "little") % R_MOD
@@ -482,9 +487,10 @@ class Prover:
             com_T, com_v = commit(T, v)
             # every challenge depends only on com_T, com_v and the keys (prover/part2.rs:55, part3.rs:69,
             # part4.rs:48): all other commitments and all openings are independent of each other
-            r2 = self.challenge([self._subtract_points(com_T, com_v)])
-            r3 = self.challenge([com_T, keys["com_S"]])
-            r, s, rp = self.challenge([com_T, keys["com_W"]], 3)
+            enc = be.g1_compress(np.stack([self._subtract_points(com_T, com_v), com_T, keys["com_S"], keys["com_W"]]))
+            r2 = self.challenge_from_encodings(enc[0:1])
+            r3 = self.challenge_from_encodings([enc[1], enc[2]])
+            r, s, rp = self.challenge_from_encodings([enc[1], enc[3]], 3)
             self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
             lap("part1")
 
