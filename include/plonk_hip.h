@@ -296,13 +296,21 @@ int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint6
 int plonk_hip_memcpy_d2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 int plonk_hip_memset_zero(plonk_hip_ctx *ctx, void *dst_dev, size_t bytes);
 /* `kzg_evaluate(gp, f, u)` (kzg.rs:63-88) for m points u of one resident polynomial: vs = m x 4,
- * proofs = m x 18 (host); m <= 64. */
+ * proofs = m x 18 (host). */
 int plonk_hip_kzg_open_many_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t n, const uint64_t *us, size_t m,
                                 uint64_t *vs, uint64_t *proofs);
 /* `kzg_commit` (kzg.rs:48-60) of `batch` resident polynomials, commitments to the host (batch x 18);
  * batch <= 64. */
 int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns, size_t batch,
                                   uint64_t *outs);
+/* A list of independent commitments and openings of resident polynomials in one call (the groups
+ * of protocols.rs:191-195, 652-667, 761-771): task k commits to polynomial k (open[k] = 0) or opens it at
+ * us[4k..4k+4) (open[k] = 1).  outs = m x 18 (commitment or proof), vs = m x 4 (f(u), zero for a
+ * commitment); m <= 64.  Queued back to back: the serial tail of one multi-scalar multiplication runs
+ * beside the accumulation of the next. */
+int plonk_hip_kzg_commit_open_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns,
+                                       const uint8_t *open, const uint64_t *us /* m x 4 */, size_t m,
+                                       uint64_t *vs, uint64_t *outs);
 /* f(wX) in place (`compose_polynomials(f, [0, w])`, polynomials.rs:80-113). */
 int plonk_hip_fr_scale_by_powers_dev(plonk_hip_ctx *ctx, void *d_coeffs, size_t n, const uint64_t w[4]);
 /* `&a * &b`: d_out receives na + nb - 1 coefficients and must not overlap a or b. */

@@ -393,6 +393,23 @@ class Backend:
         self._check(self._lib.plonk_hip_kzg_commit_many_dev(self._ctx, ptrs, ns, len(polys), _u64(outs)))
         return outs
 
+    def kzg_commit_open_many_dev(self, tasks):
+        """tasks: list of (device pointer, length, point or None): a commitment (None) or an opening at the
+        point (4 limbs).  Returns (values (m, 4) -- zero for commitments --, group elements (m, 18))."""
+        m = len(tasks)
+        ptrs = (ctypes.c_void_p * m)(*[t[0] for t in tasks])
+        ns = (ctypes.c_size_t * m)(*[t[1] for t in tasks])
+        kinds = (ctypes.c_uint8 * m)(*[0 if t[2] is None else 1 for t in tasks])
+        us = np.zeros((max(m, 1), 4), dtype=np.uint64)
+        for k, t in enumerate(tasks):
+            if t[2] is not None:
+                us[k] = _fr(t[2]).reshape(4)
+        vs = np.zeros((max(m, 1), 4), dtype=np.uint64)
+        outs = np.zeros((max(m, 1), 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_kzg_commit_open_many_dev(self._ctx, ptrs, ns, kinds, _u64(us), m, _u64(vs),
+                                                                 _u64(outs)))
+        return vs[:m], outs[:m]
+
     def fr_scale_by_powers_dev(self, d_coeffs, n, w):
         self._check(self._lib.plonk_hip_fr_scale_by_powers_dev(self._ctx, d_coeffs, n, _u64(_fr(w).reshape(4))))
 

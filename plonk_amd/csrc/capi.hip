@@ -16,6 +16,7 @@ int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.ptr) {
         // kernels already queued may still read the old allocation
         PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->tail_stream) PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->tail_stream));
         PLONK_HIP_TRY(ctx, hipFree(b.ptr));
         b.ptr = nullptr;
         b.bytes = 0;
@@ -80,16 +81,23 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
                       &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
                       &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b,
+                      &ctx->bucket_start2, &ctx->buckets2, &ctx->seg_part2, &ctx->big_list2,
                       &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws, &ctx->ntt3_ws};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
         for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
     for (int i = 0; i <= PH_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_acc[i]) (void)hipEventDestroy(ctx->ev_acc[i]);
+        if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
+    }
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -295,11 +303,38 @@ int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs
     }
     off = 0;
     for (size_t b = 0; b < batch; b++) {
-        PLONK_TRY(msm_run_dev(ctx, d_f + off, ns[b], d_out + b));
+        PLONK_TRY(msm_run_dev(ctx, d_f + off, ns[b], d_out + b, nullptr, batch > 1));
         off += ns[b];
     }
+    PLONK_TRY(msm_join(ctx));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+// v_k = f(u_k) and the opening proofs for m points of one polynomial in device memory; the suffix scan
+// of point k + 1 and its MSM run while the tail of MSM k finishes on the tail stream.
+static int open_many_core(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const uint64_t *us, size_t m, uint64_t *vs,
+                          uint64_t *proofs) {
+    const size_t scr = suffix_scan_scratch_elems(n);
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
+    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
+    for (size_t done = 0; done < m; done += 64) {
+        const size_t group = m - done < 64 ? m - done : 64;
+        for (size_t k = 0; k < group; k++) {
+            // s[0] = f(u); s[1..n) = (f - f(u)) / (X - u)
+            PLONK_TRY(suffix_scan(ctx, d_f, n, load_fr(us + 4 * (done + k)), d_s, d_s + n));
+            PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, d_out + k, nullptr, group > 1));
+            // the next scan overwrites d_s: fetch f(u) first (stream-ordered; the wait comes at the end)
+            PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * (done + k), d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        PLONK_TRY(msm_join(ctx));
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs + 18 * done, d_out, group * sizeof(G1Jac), hipMemcpyDeviceToHost,
+                                          ctx->stream));
+        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return PLONK_HIP_OK;
 }
 
@@ -310,24 +345,10 @@ int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
     if (n - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
-    size_t scr = suffix_scan_scratch_elems(n);
     PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
-    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
-    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac)));
     Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
-    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    for (size_t k = 0; k < m; k++) {
-        Fr u = load_fr(us + 4 * k);
-        PLONK_TRY(suffix_scan(ctx, d_f, n, u, d_s, d_s + n));
-        // s[0] = f(u); s[1..n) = (f - f(u)) / (X - u)
-        PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, (G1Jac *)ctx->out_stage.ptr));
-        PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * k, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-        PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs + 18 * k, ctx->out_stage.ptr, sizeof(G1Jac), hipMemcpyDeviceToHost,
-                                          ctx->stream));
-        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return PLONK_HIP_OK;
+    return open_many_core(ctx, d_f, n, us, m, vs, proofs);
 }
 
 int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t u[4], uint64_t v[4],
@@ -747,21 +768,7 @@ int plonk_hip_kzg_open_many_dev(plonk_hip_ctx *ctx, const void *d_coeffs, size_t
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
     if (n - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
-    if (m > 64) return PLONK_HIP_ERR_INVALID_ARG;
-    const size_t scr = suffix_scan_scratch_elems(n);
-    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (n + scr) * sizeof(Fr)));
-    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
-    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
-    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
-    for (size_t k = 0; k < m; k++) {
-        PLONK_TRY(suffix_scan(ctx, (const Fr *)d_coeffs, n, load_fr(us + 4 * k), d_s, d_s + n));
-        PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, d_out + k));
-        // the next scan overwrites d_s: fetch f(u) first (stream-ordered, the wait comes at the end)
-        PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * k, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs, d_out, m * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return open_many_core(ctx, (const Fr *)d_coeffs, n, us, m, vs, proofs);
 }
 
 int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns, size_t batch,
@@ -776,8 +783,51 @@ int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeff
     }
     PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
     G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
-    for (size_t b = 0; b < batch; b++) PLONK_TRY(msm_run_dev(ctx, (const Fr *)d_coeffs[b], ns[b], d_out + b));
+    for (size_t b = 0; b < batch; b++)
+        PLONK_TRY(msm_run_dev(ctx, (const Fr *)d_coeffs[b], ns[b], d_out + b, nullptr, batch > 1));
+    PLONK_TRY(msm_join(ctx));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_kzg_commit_open_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns,
+                                       const uint8_t *open, const uint64_t *us, size_t m, uint64_t *vs,
+                                       uint64_t *outs) {
+    PLONK_ENTER(ctx);
+    if (!d_coeffs || !ns || !open || !us || !vs || !outs || m > 64) return PLONK_HIP_ERR_INVALID_ARG;
+    if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
+    size_t longest = 0;
+    for (size_t k = 0; k < m; k++) {
+        if (!d_coeffs[k]) return PLONK_HIP_ERR_INVALID_ARG;
+        if (open[k]) {
+            if (ns[k] < 2) return PLONK_HIP_ERR_EMPTY_POLY;
+            if (ns[k] - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+            if (ns[k] > longest) longest = ns[k];
+        } else {
+            if (ns[k] == 0) return PLONK_HIP_ERR_EMPTY_POLY;
+            if (ns[k] > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+        }
+    }
+    if (m == 0) return PLONK_HIP_OK;
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (longest + suffix_scan_scratch_elems(longest) + 1) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    Fr *d_s = (Fr *)ctx->scratch_c.ptr;
+    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
+    memset(vs, 0, m * sizeof(Fr));
+    for (size_t k = 0; k < m; k++) {
+        const Fr *f = (const Fr *)d_coeffs[k];
+        if (open[k]) {
+            const size_t n = ns[k];
+            PLONK_TRY(suffix_scan(ctx, f, n, load_fr(us + 4 * k), d_s, d_s + n));
+            PLONK_TRY(msm_run_dev(ctx, d_s + 1, n - 1, d_out + k, nullptr, m > 1));
+            PLONK_HIP_TRY(ctx, hipMemcpyAsync(vs + 4 * k, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            PLONK_TRY(msm_run_dev(ctx, f, ns[k], d_out + k, nullptr, m > 1));
+        }
+    }
+    PLONK_TRY(msm_join(ctx));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, m * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
     PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PLONK_HIP_OK;
 }

@@ -45,6 +45,14 @@ struct plonk_hip_ctx {
     // MSM workspace
     plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
     plonk::DevBuf bucket_start, buckets, seg_part, big_list, red_a, red_b, red_lw, red_sum_a, red_sum_b;
+    // A batch of MSMs runs the serial tail (fix-up, reduction) of one MSM on `tail_stream` while the main
+    // stream already sorts and accumulates the next one: the buffers the tail reads exist twice
+    // (slot 0: the ones above) and events order the two streams.
+    plonk::DevBuf bucket_start2, buckets2, seg_part2, big_list2;
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_acc[2] = {}, ev_tail[2] = {};
+    bool tail_pending[2] = {false, false};
+    int tail_slot = 0;
     plonk::DevBuf scalars_stage, out_stage, stage_c;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
@@ -87,7 +95,12 @@ void buf_release(DevBuf &b);
 // msm.hip
 MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
 // d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
-int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out = nullptr);
+// overlap: leave the tail of this MSM running on the tail stream; the caller calls msm_join before it
+// reads d_out or returns.
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out = nullptr,
+                bool overlap = false);
+// the main stream waits for every tail still running
+int msm_join(plonk_hip_ctx *ctx);
 int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first, size_t count,
                          G1Jac *d_out);
 size_t msm_bucket_bytes();

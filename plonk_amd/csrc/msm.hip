@@ -734,9 +734,8 @@ size_t msm_bucket_bytes() { return sizeof(G1Xyzz28); }
 
 // S = sum_b (first + b + 1) B[b] over the 2^sbits buckets at B, as a Jacobian point at d_out;
 // `first` is a multiple of 2^sbits below 2^nbits (0 and sbits == nbits for a whole bucket array).
-static int reduce_buckets(plonk_hip_ctx *ctx, const G1Xyzz28 *B, uint32_t sbits, uint32_t nbits, uint32_t first,
-                          G1Jac *d_out) {
-    hipStream_t st = ctx->stream;
+static int reduce_buckets(plonk_hip_ctx *ctx, hipStream_t st, const G1Xyzz28 *B, uint32_t sbits, uint32_t nbits,
+                          uint32_t first, G1Jac *d_out) {
     const uint32_t lbits = (sbits + 1) / 2, hbits = sbits - lbits;
     const uint32_t L = 1u << lbits, H = 1u << hbits;
     PLONK_TRY(buf_reserve(ctx, ctx->red_a, ((size_t)H + L + sbits + 1) * sizeof(G1Xyzz28)));
@@ -776,12 +775,12 @@ int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts,
                            (uint32_t)count, (G1Xyzz28 *)ctx->buckets.ptr);
         B = (const G1Xyzz28 *)ctx->buckets.ptr;
     }
-    return reduce_buckets(ctx, B, sbits, (uint32_t)ctx->plan.c - 1, (uint32_t)first, d_out);
+    return reduce_buckets(ctx, ctx->stream, B, sbits, (uint32_t)ctx->plan.c - 1, (uint32_t)first, d_out);
 }
 
 // d_out: the MSM as a Jacobian point.  With d_buckets_out set (nbuckets x sizeof(G1Xyzz28) bytes of
 // device memory) the pipeline stops after the fix-up and leaves the bucket sums there instead.
-int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out) {
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out, bool overlap) {
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
     if (n > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
@@ -808,18 +807,37 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
-    PLONK_TRY(buf_reserve(ctx, ctx->bucket_start, ((size_t)nb + 2) * 4));
-    if (!d_buckets_out) PLONK_TRY(buf_reserve(ctx, ctx->buckets, (size_t)nb * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, ctx->seg_part, nseg * 2 * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, ctx->big_list, ((size_t)nb + 1) * 4));
+    // With `overlap` the tail (fix-up, reduction) runs on the tail stream and the caller queues the
+    // next MSM right away: what the tail reads is double-buffered, slot by slot.
+    overlap = overlap && !d_buckets_out && !ctx->profile;
+    if (overlap && !ctx->tail_stream) {
+        PLONK_HIP_TRY(ctx, hipStreamCreate(&ctx->tail_stream));
+        for (int i = 0; i < 2; i++) {
+            PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc[i], hipEventDisableTiming));
+            PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
+        }
+    }
+    const int slot = overlap ? ctx->tail_slot : 0;
+    if (ctx->tail_pending[slot]) {  // the tail that used this slot two MSMs ago
+        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[slot], 0));
+        ctx->tail_pending[slot] = false;
+    }
+    DevBuf &b_start = slot ? ctx->bucket_start2 : ctx->bucket_start;
+    DevBuf &b_buckets = slot ? ctx->buckets2 : ctx->buckets;
+    DevBuf &b_part = slot ? ctx->seg_part2 : ctx->seg_part;
+    DevBuf &b_big = slot ? ctx->big_list2 : ctx->big_list;
+    PLONK_TRY(buf_reserve(ctx, b_start, ((size_t)nb + 2) * 4));
+    if (!d_buckets_out) PLONK_TRY(buf_reserve(ctx, b_buckets, (size_t)nb * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, b_part, nseg * 2 * sizeof(G1Xyzz28)));
+    PLONK_TRY(buf_reserve(ctx, b_big, ((size_t)nb + 1) * 4));
 
     uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
     uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
-    uint32_t *start = (uint32_t *)ctx->bucket_start.ptr;
-    G1Xyzz28 *buckets = d_buckets_out ? (G1Xyzz28 *)d_buckets_out : (G1Xyzz28 *)ctx->buckets.ptr;
-    G1Xyzz28 *part = (G1Xyzz28 *)ctx->seg_part.ptr;
+    uint32_t *start = (uint32_t *)b_start.ptr;
+    G1Xyzz28 *buckets = d_buckets_out ? (G1Xyzz28 *)d_buckets_out : (G1Xyzz28 *)b_buckets.ptr;
+    G1Xyzz28 *part = (G1Xyzz28 *)b_part.ptr;
     const G1Affine28 *table = (const G1Affine28 *)ctx->table.ptr;
-    uint32_t *big_count = (uint32_t *)ctx->big_list.ptr, *big_list = big_count + 1;
+    uint32_t *big_count = (uint32_t *)b_big.ptr, *big_list = big_count + 1;
 
     record(ctx, PH_DIGITS);
     hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
@@ -855,12 +873,32 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
                            nb, seg_len, table, buckets, part);
     }
     record(ctx, PH_FIXUP);
-    hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, st, start, nb, seg_len, part,
+    hipStream_t ts = st;
+    if (overlap) {
+        ts = ctx->tail_stream;
+        PLONK_HIP_TRY(ctx, hipEventRecord(ctx->ev_acc[slot], st));
+        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_acc[slot], 0));
+    }
+    hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, ts, start, nb, seg_len, part,
                        buckets, g_log, per_lane, group_blocks, big_count, big_list);
     record(ctx, PH_REDUCE);
-    if (!d_buckets_out) PLONK_TRY(reduce_buckets(ctx, buckets, (uint32_t)pl.c - 1, (uint32_t)pl.c - 1, 0, d_out));
+    if (!d_buckets_out) PLONK_TRY(reduce_buckets(ctx, ts, buckets, (uint32_t)pl.c - 1, (uint32_t)pl.c - 1, 0, d_out));
     record(ctx, PH_COUNT);
+    if (overlap) {
+        PLONK_HIP_TRY(ctx, hipEventRecord(ctx->ev_tail[slot], ts));
+        ctx->tail_pending[slot] = true;
+        ctx->tail_slot ^= 1;
+    }
     PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+int msm_join(plonk_hip_ctx *ctx) {
+    for (int slot = 0; slot < 2; slot++) {
+        if (!ctx->tail_pending[slot]) continue;
+        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[slot], 0));
+        ctx->tail_pending[slot] = false;
+    }
     return PLONK_HIP_OK;
 }
 

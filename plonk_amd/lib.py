@@ -97,6 +97,9 @@ SIGNATURES = {
         ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p]),
     "plonk_hip_kzg_commit_many_dev": (
         ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_void_p), c_sizep, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_kzg_commit_open_many_dev": (
+        ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_void_p), c_sizep, ctypes.POINTER(ctypes.c_uint8), c_u64p,
+                       ctypes.c_size_t, c_u64p, c_u64p]),
     "plonk_hip_fr_scale_by_powers_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_poly_mul_dev": (
         ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

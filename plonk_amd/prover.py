@@ -551,15 +551,15 @@ class Prover:
                      (T, rp * w % R_MOD), (W, rp * w % R_MOD), (T, pow(w, 3 * ng - 1, R_MOD))]
             rows = np.zeros((len(tasks), 22), dtype=np.uint64)
             owner = deal_tasks([buf[1] for buf, _ in tasks], world)
-            for i, (buf, point) in enumerate(tasks):
-                if owner[i] != rank:
-                    continue
-                if point is None:
-                    rows[i, :18] = commit(buf)[0]
-                else:
-                    (value,), (proof,) = open_many(buf, [point])
-                    rows[i, :18] = proof
-                    rows[i, 18:] = _m(value)
+            mine = [i for i in range(len(tasks)) if owner[i] == rank]
+            if mine:  # one call: the multi-scalar multiplications are queued back to back
+                vals, points = be.kzg_commit_open_many_dev(
+                    [(tasks[i][0][0], tasks[i][0][1], None if tasks[i][1] is None else _m(tasks[i][1])) for i in mine])
+                for k, i in enumerate(mine):
+                    rows[i, :18] = points[k]
+                    rows[i, 18:] = vals[k]
+                    buf, point = tasks[i]
+                    self._log(buf, points[k], point, None if point is None else from_mont(vals[k])[0])
             lap("commit_open")
             if world > 1:
                 rows = ranks.exchange(rows, owner)

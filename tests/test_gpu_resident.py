@@ -149,3 +149,26 @@ def test_zero_and_permutation_checks_dev(backend, dev):
     copy = dev.new(n)
     backend.memcpy_d2d(copy, p, n * 32)
     assert np.array_equal(dev.get(copy, n), dev.get(p, n))
+
+
+def test_commit_open_task_list_dev(backend, dev):
+    """A mixed list of commitments and openings in one call (tails overlapped with the next accumulation)
+    against the one-at-a-time entry points."""
+    rng = np.random.default_rng(8)
+    n = 5000
+    backend.kzg_setup(rand(rng, 1)[0], n - 1, want_points=False)
+    polys = [rand(rng, m) for m in (n, 17, n - 1, 2, 300, n)]
+    points = [None, rand(rng, 1)[0], rand(rng, 1)[0], None, rand(rng, 1)[0], rand(rng, 1)[0]]
+    ptrs = [dev.put(p) for p in polys]
+    vals, outs = backend.kzg_commit_open_many_dev([(ptr, p.shape[0], u) for ptr, p, u in zip(ptrs, polys, points)])
+    for k, (p, u) in enumerate(zip(polys, points)):
+        if u is None:
+            assert np.array_equal(outs[k], backend.kzg_commit(p)) and not vals[k].any()
+        else:
+            v, proof = backend.kzg_evaluate(p, u)
+            assert np.array_equal(vals[k], v) and np.array_equal(outs[k], proof)
+    # the same list again: slots and events are reused
+    vals2, outs2 = backend.kzg_commit_open_many_dev([(ptr, p.shape[0], u) for ptr, p, u in zip(ptrs, polys, points)])
+    assert np.array_equal(vals, vals2) and np.array_equal(outs, outs2)
+    with pytest.raises(plonk_amd.ReferencePanic):  # opening a constant: kzg.rs:85
+        backend.kzg_commit_open_many_dev([(ptrs[0], n, None), (ptrs[1], 1, points[1])])
