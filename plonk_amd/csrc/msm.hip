@@ -811,7 +811,10 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     // next MSM right away: what the tail reads is double-buffered, slot by slot.
     overlap = overlap && !d_buckets_out && !ctx->profile;
     if (overlap && !ctx->tail_stream) {
-        PLONK_HIP_TRY(ctx, hipStreamCreate(&ctx->tail_stream));
+        // the tails are short chains of small kernels: let them go first when slots free up
+        int least = 0, greatest = 0;
+        PLONK_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        PLONK_HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamDefault, greatest));
         for (int i = 0; i < 2; i++) {
             PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc[i], hipEventDisableTiming));
             PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
