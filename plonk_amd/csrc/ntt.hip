@@ -158,13 +158,14 @@ static int build_two_level29(plonk_hip_ctx *ctx, const Fr &base, size_t count, c
     return PLONK_HIP_OK;
 }
 
-int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, const Fr &w) {
+int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, const Fr &w, size_t stride) {
+    if (stride == 0) stride = n;
     if (n == 0 || batch == 0) return PLONK_HIP_OK;
     if (n > 0xffffffffull || batch > 65535) return PLONK_HIP_ERR_INVALID_ARG;
     const Tw29 *lo, *hi;
     PLONK_TRY(build_two_level29(ctx, w, n, &lo, &hi));
     hipLaunchKernelGGL(k_scale_two_level, dim3(cdiv(n, 256), cdiv(batch, kScaleGroup)), dim3(256), 0, ctx->stream,
-                       d_data, n, n, (unsigned)batch, lo, hi);
+                       d_data, n, stride, (unsigned)batch, lo, hi);
     return PLONK_HIP_OK;
 }
 
@@ -730,7 +731,9 @@ int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch
     PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd));
     Fr ninv = fe_inv(fr_from_u64(n));
     PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv));
-    PLONK_TRY(scale_by_powers(ctx, d_f, n, batch, fe_inv(g)));
+    // only the k quotient coefficients are shifted back: the upper half is zero exactly when it was zero
+    // before (every factor is a non-zero power), and that is all the divisibility test below reads
+    PLONK_TRY(scale_by_powers(ctx, d_f, k, batch, fe_inv(g), n));
     if (d_divisible) {
         hipLaunchKernelGGL(k_set_int, dim3(cdiv(batch, 256)), dim3(256), 0, ctx->stream, d_divisible, batch, 1);
         hipLaunchKernelGGL(k_check_zero, dim3(cdiv(k, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_f, k, k, n,

@@ -8,7 +8,8 @@ namespace plonk {
 size_t suffix_scan_scratch_elems(size_t n);
 int suffix_scan(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const Fr &u, Fr *d_s, Fr *d_scratch);
 // data[b][i] *= w^i for `batch` vectors of n elements stored back to back.
-int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, const Fr &w);
+// the first n elements of `batch` vectors `stride` elements apart (0: n) are multiplied by w^i
+int scale_by_powers(plonk_hip_ctx *ctx, Fr *d_data, size_t n, size_t batch, const Fr &w, size_t stride = 0);
 // q[j] = sum_{m>=1} f[j + m*k], j < n - k.
 int div_vanishing(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, size_t k, Fr *d_q);
 
