@@ -218,6 +218,9 @@ def main():
     # ranks (ranks then share devices and the 144-byte partials are staged through the host)
     backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count()
+    if world > torch.cuda.device_count():
+        # ranks share a GPU (rehearsal): keep each MSM on one stream, see plonk_hip.h
+        os.environ.setdefault("PLONK_HIP_SERIAL_TAILS", "1")
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:
@@ -294,6 +297,8 @@ def main():
     if world > 1 and args.prover_log_gates and not args.no_extras:
         try:
             import datetime
+            import faulthandler
+            faulthandler.dump_traceback_later(75, exit=False)  # a stuck rank shows where it is
             group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=90))
             ranks = sharding.TaskExchange(group=group)
             sec, _, checked = time_prover(args.prover_log_gates, device_index, ranks,
@@ -302,7 +307,10 @@ def main():
             dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX, group=group)
             dist.all_reduce(t[1:2], op=dist.ReduceOp.MIN, group=group)
             shared_prover = (float(t[0]), bool(t[1] > 0.5))
+            faulthandler.cancel_dump_traceback_later()
         except Exception as exc:  # noqa: BLE001 -- reported in the bench line
+            import traceback
+            traceback.print_exc()
             shared_prover = "failed: %r" % (exc,)
 
     if rank == 0:

@@ -22,6 +22,7 @@
 //                    plain sums R, LDS tree sums of every level's LW, Horner over the levels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "context.hpp"
 #include "coop28.cuh"
@@ -809,12 +810,17 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
     // With `overlap` the tail (fix-up, reduction) runs on the tail stream and the caller queues the
     // next MSM right away: what the tail reads is double-buffered, slot by slot.
-    overlap = overlap && !d_buckets_out && !ctx->profile;
+    // PLONK_HIP_SERIAL_TAILS=1 keeps everything on one stream (e.g. many processes sharing one GPU, where
+    // a stream that waits for an event of a stream the hardware has not scheduled can stall for long)
+    static const bool serial_tails = [] {
+        const char *v = getenv("PLONK_HIP_SERIAL_TAILS");
+        return v && v[0] == '1';
+    }();
+    overlap = overlap && !d_buckets_out && !ctx->profile && !serial_tails;
     if (overlap && !ctx->tail_stream) {
-        // the tails are short chains of small kernels: let them go first when slots free up
-        int least = 0, greatest = 0;
-        PLONK_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        PLONK_HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamDefault, greatest));
+        // default priority on purpose: a high-priority stream that waits for an event of the main stream
+        // can keep that stream from being scheduled when queues of several processes share a pipe
+        PLONK_HIP_TRY(ctx, hipStreamCreate(&ctx->tail_stream));
         for (int i = 0; i < 2; i++) {
             PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc[i], hipEventDisableTiming));
             PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
