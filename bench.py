@@ -295,9 +295,9 @@ def main():
     # a failure on one rank ends in an error note instead of a stuck job
     shared_prover = None
     if world > 1 and args.prover_log_gates and not args.no_extras:
+        import faulthandler
         try:
             import datetime
-            import faulthandler
             faulthandler.dump_traceback_later(75, exit=False)  # a stuck rank shows where it is
             group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=90))
             ranks = sharding.TaskExchange(group=group)
@@ -311,6 +311,7 @@ def main():
         except Exception as exc:  # noqa: BLE001 -- reported in the bench line
             import traceback
             traceback.print_exc()
+            faulthandler.cancel_dump_traceback_later()
             shared_prover = "failed: %r" % (exc,)
 
     if rank == 0:
