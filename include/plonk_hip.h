@@ -338,6 +338,16 @@ int plonk_hip_fr_is_zero_dev(plonk_hip_ctx *ctx, const void *d_x, size_t n, int 
 /* d_num[i] <- prod_{j<=i} d_num[j] / d_den[j] (protocols.rs:345-353, 571-588); d_den is overwritten with
  * the inverses.  PLONK_HIP_ERR_ZERO_DENOMINATOR like the host form. */
 int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n);
+/* plonk_hip_fr_ratio_prefix_product_dev for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arithmetic on the same kernels, but the call allocates and frees nothing and never
+ * waits: the partial products of the scan live in a static array of the library's code object (270 336
+ * bytes, held by every GPU the library runs on until the process ends), and a zero denominator is reported
+ * through *d_zero_flag (a device int the caller owns: 0 = fine, 1 = some d_den[i] was zero and d_num is
+ * unspecified) instead of an error code.  n <= 2^24, else PLONK_HIP_ERR_INVALID_ARG.  All contexts on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race. */
+int plonk_hip_fr_ratio_prefix_product_dev_noalloc(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n,
+                                                  int *d_zero_flag);
 
 #ifdef __cplusplus
 }

@@ -444,6 +444,10 @@ class Backend:
     def fr_ratio_prefix_product_dev(self, d_num, d_den, n):
         self._check(self._lib.plonk_hip_fr_ratio_prefix_product_dev(self._ctx, d_num, d_den, n))
 
+    def fr_ratio_prefix_product_dev_noalloc(self, d_num, d_den, n, d_zero_flag):
+        """The same through the entry point that allocates nothing; d_zero_flag: a device int."""
+        self._check(self._lib.plonk_hip_fr_ratio_prefix_product_dev_noalloc(self._ctx, d_num, d_den, n, d_zero_flag))
+
     def fr_ntt_mixed_dev(self, dptr, n, batch=1, inverse=False):
         self._check(self._lib.plonk_hip_fr_ntt_mixed_dev(self._ctx, dptr, n, batch, 1 if inverse else 0))
 

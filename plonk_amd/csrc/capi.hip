@@ -35,6 +35,31 @@ void buf_release(DevBuf &b) {
 
 }  // namespace plonk
 
+// Scratch of plonk_hip_fr_ratio_prefix_product_dev_noalloc: the block totals of the running product
+// for up to kStaticMaxElems elements.  One copy per GPU, in the code object's own memory; every
+// context created on a GPU resolves that GPU's address once, below.
+static constexpr size_t kStaticMaxElems = (size_t)1 << 24;
+static constexpr size_t kStaticScratchBytes = 8448 * sizeof(Fr);  // 8198 elements needed at 2^24
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+static std::mutex g_static_mu;
+static void *g_static_ptr[256];  // per device ordinal
+
+// The device must be current on the calling thread.
+static hipError_t resolve_static_scratch(int device, void **out) {
+    if (device < 0 || device >= 256) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(g_static_mu);
+    if (!g_static_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_static_ptr[device] = ptr;
+    }
+    *out = g_static_ptr[device];
+    return hipSuccess;
+}
+
 static int bind(plonk_hip_ctx *ctx) {
     PLONK_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return PLONK_HIP_OK;
@@ -72,6 +97,10 @@ int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
             delete ctx;
             return PLONK_HIP_ERR_HIP;
         }
+    }
+    if (resolve_static_scratch(device, &ctx->static_scratch) != hipSuccess) {
+        plonk_hip_ctx_destroy(ctx);
+        return PLONK_HIP_ERR_HIP;
     }
     *out = ctx;
     return PLONK_HIP_OK;
@@ -917,6 +946,27 @@ int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void 
     PLONK_TRY(prefix_scan(ctx, (Fr *)d_num, n, true, (Fr *)ctx->scalars_stage.ptr));
     PLONK_TRY(read_flag(ctx, d_flag, &flag));
     return flag ? PLONK_HIP_ERR_ZERO_DENOMINATOR : PLONK_HIP_OK;
+}
+
+// The same computation with no allocation anywhere: the running product's block totals go to this
+// GPU's static scratch array, the zero-denominator report to the caller's device word, and nothing is
+// read back, so the call only enqueues.
+int plonk_hip_fr_ratio_prefix_product_dev_noalloc(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n,
+                                                  int *d_zero_flag) {
+    PLONK_ENTER(ctx);
+    if (((!d_num || !d_den) && n) || !d_zero_flag) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n > kStaticMaxElems || prefix_scan_scratch_elems(n) * sizeof(Fr) > kStaticScratchBytes) {
+        ctx->last_error = "plonk_hip_fr_ratio_prefix_product_dev_noalloc: n exceeds 2^24 elements";
+        return PLONK_HIP_ERR_INVALID_ARG;
+    }
+    if (!ctx->static_scratch) return PLONK_HIP_ERR_HIP;
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(d_zero_flag, 0, sizeof(int), ctx->stream));
+    if (n == 0) return PLONK_HIP_OK;
+    PLONK_TRY(batch_inverse(ctx, (Fr *)d_den, n, d_zero_flag));
+    PLONK_TRY(pointwise_mul(ctx, (const Fr *)d_num, (const Fr *)d_den, (Fr *)d_num, n));
+    PLONK_TRY(prefix_scan(ctx, (Fr *)d_num, n, true, (Fr *)ctx->static_scratch));
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
 }
 
 }  // extern "C"

@@ -66,6 +66,9 @@ struct plonk_hip_ctx {
     plonk::DevBuf twiddle[2][33];
     bool ntt_lds_opt_in = false;  // large dynamic LDS enabled for the transform kernels on this device
 
+    // this device's copy of the library's static scratch array (capi.hip), resolved at creation
+    void *static_scratch = nullptr;
+
     bool profile = false;
     hipEvent_t ev[plonk::PH_COUNT + 1] = {};
     float phase_ms[plonk::PH_COUNT] = {};

@@ -115,6 +115,8 @@ SIGNATURES = {
                        ctypes.POINTER(ctypes.c_int)]),
     "plonk_hip_fr_is_zero_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),
     "plonk_hip_fr_ratio_prefix_product_dev": (ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_hip_fr_ratio_prefix_product_dev_noalloc": (
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_fr_ratio_prefix_product": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_poly_mul": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
