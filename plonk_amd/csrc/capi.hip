@@ -119,7 +119,11 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
                       &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws, &ctx->ntt3_ws};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
-        for (int i = 0; i < 33; i++) buf_release(ctx->twiddle[d][i]);
+        for (int i = 0; i < 33; i++) {
+            buf_release(ctx->twiddle[d][i]);
+            buf_release(ctx->coset_tab[d][i]);
+            for (int j = 0; j < 33; j++) buf_release(ctx->ntt_corr[d][i][j]);
+        }
     for (int i = 0; i <= PH_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 2; i++) {

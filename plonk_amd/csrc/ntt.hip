@@ -12,8 +12,20 @@
 // + DIT); the quotient pipeline chains DIF -> pointwise -> DIT and never permutes.
 // Inside a pass the butterflies run on 29-bit limbs (field29.cuh) with lazy reduction; every lane
 // keeps 8 elements in registers and does up to 3 stages (12 butterflies) per LDS round trip.
-// Twiddles omega^e, e < n/2, are precomputed per size and direction (as w * 2^261 in 29-bit
-// limbs) and cached in the context.
+//
+// Twiddles (four-step form).  A pass over [s0, s1) is a plain transform of 2^(s1-s0) points on
+// every tile: its butterflies use the roots of unity of THAT size, which depend on the in-tile
+// index j only (a table of 2^(s1-s0-1) entries that stays in the caches; the stages on the three
+// lowest in-tile bits use 1, omega_4, omega_8 and omega_8^3 from scalar registers, and the
+// multiplications by 1 are skipped: 7 of every 40 butterflies of a 10-stage pass).  What the true
+// twiddle omega_(2^s1)^((j_low << s0 | t_lo) << ...) has on top of that is collected into ONE factor
+// per element, omega_(2^s1)^(t_lo * rev(j)), applied when a strided pass stores (DIF) or loads
+// (DIT).  Those factors come from a table laid out like the data ((j << s0) | t_lo), so they are
+// read in the same contiguous rows as the data, and a batch is dealt to the eight XCDs by tile
+// rather than by vector, so that one XCD's L2 serves a table row to all vectors of the batch.
+// A coset shift (f(gX) before a forward transform, g^-i / n after an inverse one) is one more
+// table of per-element factors applied at the first load or the last store: no separate pass.
+// All tables hold w * 2^261 in 29-bit limbs and are cached in the context per size and direction.
 #include "context.hpp"
 #include "field29.cuh"
 #include "poly.hpp"
@@ -92,6 +104,35 @@ __global__ __launch_bounds__(256) void k_twiddle29(const Fr *__restrict__ lo, co
     t.v = fr29_twiddle_from(v);
     t.pad[0] = t.pad[1] = t.pad[2] = 0;
     out[e] = t;
+}
+// the same with every entry multiplied by `factor` (a coset table with 1/n folded in)
+__global__ __launch_bounds__(256) void k_twiddle29_scaled(const Fr *__restrict__ lo, const Fr *__restrict__ hi,
+                                                         size_t count, Fr factor, Tw29 *__restrict__ out) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    Fr v = fe_mul(lo[e & 1023], factor);
+    if (e >> 10) v = fe_mul(v, hi[e >> 10]);
+    Tw29 t;
+    t.v = fr29_twiddle_from(v);
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    out[e] = t;
+}
+// Correction factors of a strided pass over the stages [s0, s1): out[(j << s0) | t] = w^(t * rev(j)),
+// w the primitive 2^s1-th root the lo / hi tables are powers of, rev over the s1 - s0 bits of j.
+__global__ __launch_bounds__(256) void k_correction29(const Fr *__restrict__ lo, const Fr *__restrict__ hi, uint32_t s0,
+                                                     uint32_t s1, Tw29 *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> s1) return;
+    const uint32_t k = s1 - s0;
+    const uint64_t t = i & (((size_t)1 << s0) - 1);
+    const uint64_t jr = __brev((uint32_t)(i >> s0)) >> (32 - k);
+    const uint64_t e = (t * jr) & (((uint64_t)1 << s1) - 1);
+    Fr v = lo[e & 1023];
+    if (e >> 10) v = fe_mul(v, hi[e >> 10]);
+    Tw29 o;
+    o.v = fr29_twiddle_from(v);
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    out[i] = o;
 }
 // out[i] = base^i * 2^261 in 29-bit limbs (the multiplier form of the lazy product)
 __global__ __launch_bounds__(256) void k_pow_table29(PowSeed seed, uint32_t count, Tw29 *__restrict__ out) {
@@ -185,6 +226,47 @@ static int get_twiddles(plonk_hip_ctx *ctx, uint32_t log_n, bool inverse, const 
     return PLONK_HIP_OK;
 }
 
+// w_(2^s1)^(t * rev(j)) at (j << s0) | t for the strided pass over [s0, s1)
+static int get_correction(plonk_hip_ctx *ctx, uint32_t s0, uint32_t s1, bool inverse, const Tw29 **out) {
+    DevBuf &b = ctx->ntt_corr[inverse ? 1 : 0][s1][s0];
+    const size_t count = (size_t)1 << s1;
+    if (!b.ptr) {
+        Fr w = fr_root_of_unity(s1);
+        if (inverse) w = fe_inv(w);
+        const Fr *lo, *hi;
+        PLONK_TRY(build_two_level(ctx, w, count, &lo, &hi));
+        PLONK_TRY(buf_reserve(ctx, b, count * sizeof(Tw29)));
+        hipLaunchKernelGGL(k_correction29, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, lo, hi, s0, s1,
+                           (Tw29 *)b.ptr);
+    }
+    *out = (const Tw29 *)b.ptr;
+    return PLONK_HIP_OK;
+}
+
+// Coset factors for vectors of 2^log_n elements: pre[i] = shift^i (forward transform of f(shift X)),
+// post[i] = shift^-i / n (after an inverse transform).  One shift is cached per size and direction.
+static int get_coset_table(plonk_hip_ctx *ctx, uint32_t log_n, const Fr &shift, bool inverse, const Tw29 **out) {
+    const int d = inverse ? 1 : 0;
+    DevBuf &b = ctx->coset_tab[d][log_n];
+    const size_t n = (size_t)1 << log_n;
+    if (!b.ptr || !ctx->coset_ok[d][log_n] || !fe_eq(ctx->coset_shift[d][log_n], shift)) {
+        ctx->coset_ok[d][log_n] = false;
+        const Fr *lo, *hi;
+        PLONK_TRY(build_two_level(ctx, inverse ? fe_inv(shift) : shift, n, &lo, &hi));
+        PLONK_TRY(buf_reserve(ctx, b, n * sizeof(Tw29)));
+        if (inverse) {
+            hipLaunchKernelGGL(k_twiddle29_scaled, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, lo, hi, n,
+                               fe_inv(fr_from_u64(n)), (Tw29 *)b.ptr);
+        } else {
+            hipLaunchKernelGGL(k_twiddle29, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, lo, hi, n, (Tw29 *)b.ptr);
+        }
+        ctx->coset_shift[d][log_n] = shift;
+        ctx->coset_ok[d][log_n] = true;
+    }
+    *out = (const Tw29 *)b.ptr;
+    return PLONK_HIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // butterfly passes
 // ------------------------------------------------------------------------------------------
@@ -204,17 +286,32 @@ __device__ __forceinline__ void lds_put(uint32_t *tile, uint32_t j, const Fr29 &
     for (int i = 0; i < R29::N; i++) p[i] = v.l[i];
 }
 
-// One round: G butterfly stages on the in-tile bits [b0, b0 + G).  A call handles NE elements:
-// NE / 2^G groups of 2^G elements whose tile indices differ exactly in those bits; `item` is the
-// work item's index inside the tile (tile_n / 8 of them).
-// Bounds (units of 2^255, capacity 64; r = 0.906): DIT lets values grow by at most 1.81 per stage
-// (19.4 after the 10 stages of a pass, reduced when the pass stores).  DIF lets the sums of a round
-// double per stage and reduces them once at the end of the round: with every element below
-// B = 4.1 at the start, sums reach 8 B = 32.6, one reduction step brings them below
-// 1 + 0.0943 * 32 < B again, a subtrahend is at most 4 B < 19 r, and products stay below 1.4.
-template <bool DIF, int G, int NE>
-__device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_t b0, uint32_t s0, uint32_t log_n,
-                                          size_t t_lo, const Tw29 *__restrict__ tw) {
+// One round: G butterfly stages on the in-tile bits [b0, b0 + G) of a tile of 2^k elements.  A call
+// handles NE elements: NE / 2^G groups of 2^G elements whose tile indices differ exactly in those
+// bits; `item` is the work item's index inside the tile (tile_n / 8 of them).  Stage b0 + bb of a
+// group multiplies by w^((j mod 2^(b0 + bb)) << (k - 1 - b0 - bb)), w the primitive 2^k-th root the
+// table `tw` holds the powers of.
+// Z marks the round on the lowest bits (b0 == 0): there j mod 2^bb is the group position itself, so
+// the factors are the same for every lane (scalar loads) and those with exponent 0 are skipped.
+//
+// Bounds (units of 2^255, capacity 64; r = 0.906).
+// DIF: every element enters a round below B = 4.2; sums double per stage (8 B = 33.6 at most), a
+//   subtrahend is at most 4 B < 19 r, a product is below 1.4, and at the end of the round every value
+//   that is not a fresh product takes one reduction step, which brings it below 1 + 0.0943 * 33 < B.
+//   A difference that is NOT multiplied (Z round, exponent 0) is below B' + 17.2 with B' the bound
+//   of its operands (4.2, 8.4 or 16.8): it is reduced at once (below 3.4) except after the last
+//   stage, where the round's closing reduction takes care of it.
+// DIT: elements enter the first (Z) round below 2 (fresh from memory, or a product); its unmultiplied
+//   differences add 3 r, 6 r, 12 r (each at least the subtrahend's bound 2, 4.72, 10.15): below 21.1
+//   after the round.  Every later stage adds at most 2 r = 1.81: below 36 after 11 stages.
+template <int BB>
+struct DitZeroK {
+    static constexpr int value = BB == 0 ? 3 : (BB == 1 ? 6 : 12);
+};
+
+template <bool DIF, int G, int NE, bool Z>
+__device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_t b0, uint32_t k,
+                                          const Tw29 *__restrict__ tw) {
     constexpr uint32_t GROUP = 1u << G, GPT = (uint32_t)NE >> G, TW_PER_GROUP = GROUP - 1;
     Fr29 x[NE];
     uint32_t jj[NE];
@@ -230,17 +327,23 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
         }
     }
     // Twiddles of the whole round, requested up front so that their latencies overlap: stage bb
-    // of a group needs 2^bb distinct factors (one per value of the group bits below bb).
-    Fr29 twr[GPT * TW_PER_GROUP];
+    // of a group needs 2^bb distinct factors (one per value of the group bits below bb).  In the Z
+    // round they do not depend on the lane: one set for all groups, from uniform addresses.
+    Fr29 twr[Z ? TW_PER_GROUP : GPT * TW_PER_GROUP];
 #pragma unroll
-    for (uint32_t u = 0; u < GPT; u++) {
+    for (uint32_t u = 0; u < (Z ? 1u : GPT); u++) {
 #pragma unroll
         for (int bb = 0; bb < G; bb++) {
-            const uint32_t st = s0 + b0 + bb;  // global stage: half-span 2^st
             const uint32_t emask = (1u << (b0 + bb)) - 1;
 #pragma unroll
             for (uint32_t cl = 0; cl < (1u << bb); cl++) {
-                const size_t e = ((((size_t)(jj[u * GROUP + cl] & emask)) << s0) | t_lo) << (log_n - 1 - st);
+                if (Z && cl == 0) continue;  // exponent 0
+                uint32_t e;
+                if (Z) {
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cl << (k - 1 - bb)));
+                } else {
+                    e = (jj[u * GROUP + cl] & emask) << (k - 1 - b0 - bb);
+                }
                 twr[u * TW_PER_GROUP + ((1u << bb) - 1) + cl] = tw[e].v;
             }
         }
@@ -254,7 +357,24 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
             for (uint32_t c = 0; c < GROUP; c++) {
                 if (c & (1u << bb)) continue;
                 const uint32_t lo = u * GROUP + c, hi = lo | (1u << bb);
-                const Fr29 &w = twr[u * TW_PER_GROUP + ((1u << bb) - 1) + (c & ((1u << bb) - 1))];
+                const uint32_t cl = c & ((1u << bb) - 1);
+                if (Z && cl == 0) {
+                    // factor 1
+                    if (DIF) {
+                        Fr29 sum = fr29_add_lazy(x[lo], x[hi]);
+                        Fr29 d = fr29_sub_lazy<19>(x[lo], x[hi]);
+                        x[hi] = bb == 0 ? d : fr29_reduce_step(d);
+                        x[lo] = sum;
+                    } else {
+                        Fr29 t = x[hi];
+                        if (bb == 0) x[hi] = fr29_sub_lazy<DitZeroK<0>::value>(x[lo], t);
+                        if (bb == 1) x[hi] = fr29_sub_lazy<DitZeroK<1>::value>(x[lo], t);
+                        if (bb == 2) x[hi] = fr29_sub_lazy<DitZeroK<2>::value>(x[lo], t);
+                        x[lo] = fr29_add_lazy(x[lo], t);
+                    }
+                    continue;
+                }
+                const Fr29 &w = twr[(Z ? 0u : u * TW_PER_GROUP) + ((1u << bb) - 1) + cl];
                 if (DIF) {
                     Fr29 sum = fr29_add_lazy(x[lo], x[hi]);
                     x[hi] = fr29_mul_lazy(fr29_sub_lazy<19>(x[lo], x[hi]), w);
@@ -268,33 +388,61 @@ __device__ __forceinline__ void ntt_round(uint32_t *tile, uint32_t item, uint32_
         }
     }
     if (DIF) {
-        // the elements that were sums in the last stage (group bit 0 clear)
+        // what is not a fresh product: the sums of the last stage (group bit 0 clear), and in the Z
+        // round its differences as well
 #pragma unroll
-        for (uint32_t e = 0; e < (uint32_t)NE; e += 2) x[e] = fr29_reduce_step(x[e]);
+        for (uint32_t e = 0; e < (uint32_t)NE; e += (Z ? 1 : 2)) x[e] = fr29_reduce_step(x[e]);
     }
 #pragma unroll
     for (uint32_t e = 0; e < (uint32_t)NE; e++) lds_put(tile, jj[e], x[e]);
 }
 
+struct PassArgs {
+    size_t batch_stride;
+    uint32_t log_n, s0, s1, tpb_log;
+    uint32_t batch, tile_blocks;  // vectors in this launch; blocks per vector
+    int do_scale, canonical_out, in_map, out_map, xcd_map;
+    Fr29 scale, scale_upper;
+};
+
 // One pass over the stages [s0, s1) (3 <= s1 - s0 <= 11).  A block owns `tiles_per_block`
 // consecutive tiles (several when tiles are small, so that all lanes have work).  Elements
 // cross HBM as 8 x 32-bit limbs (values below 2^256; canonical when `canonical_out` is set, as
-// on the last pass).  `scale` (w * 2^261 form) multiplies every output when do_scale is 1; with
-// do_scale 2 (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
+// on the last pass).
+//   tw    powers of the primitive 2^(s1-s0)-th root (direction as the transform's)
+//   corr  strided passes: the per-element factors described at the top of the file, at (j << s0) | t_lo
+//         (DIF multiplies when it stores, DIT when it loads); null on the pass with s0 = 0
+//   pre   a factor per input element, by address (coset shift of a forward transform), or null
+//   post  a factor per output element, by address (coset shift and 1/n of an inverse transform), or null
+// `scale` (w * 2^261 form) multiplies every output when do_scale is 1 and post is null; with do_scale 2
+// (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
+// Grid: tile_blocks * batch blocks.  With xcd_map the block index is read as (slot, xcd) = (L / 8,
+// L % 8), slot = group * batch + vector, and the block works on tile block 8 * group + xcd: blocks that
+// the hardware deals to one XCD (L % 8 equal) and that follow each other share their table rows.
 template <bool DIF, int GMAX>
-__global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *src, Fr *dst, uint32_t log_n, uint32_t s0, uint32_t s1,
-                                                  uint32_t tpb_log, const Tw29 *__restrict__ tw, size_t batch_stride,
-                                                  Fr29 scale, Fr29 scale_upper, int do_scale, int canonical_out,
-                                                  int in_map, int out_map) {
+__global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *src, Fr *dst, const Tw29 *__restrict__ tw,
+                                                  const Tw29 *__restrict__ corr, const Tw29 *__restrict__ pre,
+                                                  const Tw29 *__restrict__ post, PassArgs a) {
     extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t log_n = a.log_n, s0 = a.s0, s1 = a.s1, tpb_log = a.tpb_log;
     const uint32_t k = s1 - s0;
     const uint32_t tile_n = 1u << k;
     const uint32_t tile_words = 9u * tile_n + (tile_n >> 5) + 1;
     const uint32_t block_elems = tile_n << tpb_log;
-    const Fr *vec_in = src + (size_t)blockIdx.y * batch_stride;
-    Fr *vec = dst + (size_t)blockIdx.y * batch_stride;
-    const size_t first_tile = (size_t)blockIdx.x << tpb_log;
+    uint32_t tile_block, vec_index;
+    if (a.xcd_map) {
+        const uint32_t slot = blockIdx.x >> 3;
+        tile_block = (slot / a.batch) * 8 + (blockIdx.x & 7);
+        vec_index = slot % a.batch;
+    } else {
+        tile_block = blockIdx.x % a.tile_blocks;
+        vec_index = blockIdx.x / a.tile_blocks;
+    }
+    const Fr *vec_in = src + (size_t)vec_index * a.batch_stride;
+    Fr *vec = dst + (size_t)vec_index * a.batch_stride;
+    const size_t first_tile = (size_t)tile_block << tpb_log;
     const size_t s0_mask = ((size_t)1 << s0) - 1;
+    const int in_map = a.in_map, out_map = a.out_map;
 
     // Neighbouring lanes take neighbouring addresses: in the pass with s0 = 0 a tile is contiguous
     // (j runs fastest); in a strided pass the tiles of a block are adjacent columns (the tile
@@ -313,7 +461,12 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
         const uint32_t tb = tile_fastest_in ? q & ((1u << tpb_log) - 1) : q >> k;
         const uint32_t j = tile_fastest_in ? q >> tpb_log : q & (tile_n - 1);
-        lds_put(lds + tb * tile_words, j, fr29_pack(vec_in[address(in_map, first_tile + tb, j)]));
+        const size_t T = first_tile + tb;
+        const size_t idx = address(in_map, T, j);
+        Fr29 v = fr29_pack(vec_in[idx]);
+        if (pre) v = fr29_mul_lazy(v, pre[idx].v);
+        if (!DIF && corr) v = fr29_mul_lazy(v, corr[((size_t)j << s0) | (T & s0_mask)].v);
+        lds_put(lds + tb * tile_words, j, v);
     }
     __syncthreads();
 
@@ -323,30 +476,27 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
     const uint32_t items_per_tile = tile_n >> GMAX, items = items_per_tile << tpb_log;
     const uint32_t nrounds = (k + GMAX - 1) / GMAX;
     for (uint32_t r = 0; r < nrounds; r++) {
-        // DIT walks the in-tile bits upwards, DIF downwards; the last round takes what is left
-        uint32_t g, b0;
-        if (DIF) {
-            uint32_t top = k - GMAX * r;
-            g = top < (uint32_t)GMAX ? top : (uint32_t)GMAX;
-            b0 = top - g;
-        } else {
-            b0 = GMAX * r;
-            g = k - b0 < (uint32_t)GMAX ? k - b0 : (uint32_t)GMAX;
-        }
+        // round q works on the in-tile bits [GMAX q, GMAX q + g): DIT walks them upwards, DIF
+        // downwards; the round on the highest bits takes what is left (g <= GMAX)
+        const uint32_t b0 = GMAX * (DIF ? nrounds - 1 - r : r);
+        const uint32_t g = k - b0 < (uint32_t)GMAX ? k - b0 : (uint32_t)GMAX;
         for (uint32_t w = threadIdx.x; w < items; w += blockDim.x) {
             const uint32_t tb = w / items_per_tile, item = w % items_per_tile;
-            const size_t t_lo = (first_tile + tb) & s0_mask;
             uint32_t *tile = lds + tb * tile_words;
             if (GMAX == 3 && g == 3) {
-                ntt_round<DIF, 3, 8>(tile, item, b0, s0, log_n, t_lo, tw);
+                if (b0 == 0) {
+                    ntt_round<DIF, 3, 8, true>(tile, item, 0, k, tw);
+                } else {
+                    ntt_round<DIF, 3, 8, false>(tile, item, b0, k, tw);
+                }
             } else if (g == 2) {
                 // groups of four, one after the other (for GMAX = 3 this keeps the register
                 // footprint of the rarely taken branch below that of the three-stage round)
 #pragma unroll 1
                 for (uint32_t h = 0; h < NE / 4; h++)
-                    ntt_round<DIF, 2, 4>(tile, (NE / 4) * item + h, b0, s0, log_n, t_lo, tw);
+                    ntt_round<DIF, 2, 4, false>(tile, (NE / 4) * item + h, b0, k, tw);
             } else {
-                ntt_round<DIF, 1, (int)NE>(tile, item, b0, s0, log_n, t_lo, tw);
+                ntt_round<DIF, 1, (int)NE, false>(tile, item, b0, k, tw);
             }
         }
         __syncthreads();
@@ -355,16 +505,24 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
     for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
         const uint32_t tb = tile_fastest_out ? q & ((1u << tpb_log) - 1) : q >> k;
         const uint32_t j = tile_fastest_out ? q >> tpb_log : q & (tile_n - 1);
-        const size_t idx = address(out_map, first_tile + tb, j);
+        const size_t T = first_tile + tb;
+        const size_t idx = address(out_map, T, j);
         Fr29 v = lds_get(lds + tb * tile_words, j);
-        if (do_scale == 2) {
-            v = fr29_mul_lazy(v, (idx >> (log_n - 1)) ? scale_upper : scale);
-        } else if (do_scale) {
-            v = fr29_mul_lazy(v, scale);  // below r + 20/64 * 2^255 < 2r
-        } else {
+        bool product = false;  // a product is below 2 r
+        if (DIF && corr) {
+            v = fr29_mul_lazy(v, corr[((size_t)j << s0) | (T & s0_mask)].v);
+            product = true;
+        }
+        if (post) {
+            v = fr29_mul_lazy(v, post[idx].v);
+        } else if (a.do_scale == 2) {
+            v = fr29_mul_lazy(v, (idx >> (log_n - 1)) ? a.scale_upper : a.scale);
+        } else if (a.do_scale) {
+            v = fr29_mul_lazy(v, a.scale);
+        } else if (!product) {
             v = fr29_reduce_below_2_256(v);
         }
-        if (canonical_out) v = fr29_cond_sub(v);
+        if (a.canonical_out) v = fr29_cond_sub(v);
         vec[idx] = fr29_unpack(v);
     }
 }
@@ -455,14 +613,19 @@ static PassPlan make_plan(uint32_t log_n) {
 // DIF (natural -> bit-reversed) or DIT (bit-reversed -> natural) butterflies over `batch`
 // vectors of 2^log_n elements; `scale` (if given, radix-2^256 Montgomery form) multiplies
 // every output element in the last pass.  Outputs are canonical.
+// pre / post (log_n >= 3): tables of one factor per element, by address, applied when the first pass
+// loads (its input is in natural order for DIF) or the last pass stores (natural order for DIT); post
+// replaces `scale`.
 // With `natural` set (3 <= log_n <= kMaxNaturalLog) the permutation is folded into the passes:
 // DIF then takes natural order to natural order, DIT likewise; transforms of more than one pass
 // go through the context's transform workspace (the scattering pass cannot work in place).
 static constexpr uint32_t kMaxNaturalLog = 20;
 static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, bool inverse_tw, bool dif,
-                      const Fr *scale, const Fr *scale_upper = nullptr, bool natural = false) {
+                      const Fr *scale, const Fr *scale_upper = nullptr, bool natural = false,
+                      const Tw29 *pre = nullptr, const Tw29 *post = nullptr) {
     const size_t n = (size_t)1 << log_n;
     if (log_n <= 2) {
+        if (pre || post) return PLONK_HIP_ERR_INVALID_ARG;
         // 2 or 4 points: natural-order transform plus the permutation the caller expects;
         // omega_4 (or its inverse) is the only non-trivial factor
         Fr w4 = fr_root_of_unity(2);
@@ -478,8 +641,7 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         }
         return PLONK_HIP_OK;
     }
-    const Tw29 *tw;
-    PLONK_TRY(get_twiddles(ctx, log_n, inverse_tw, &tw));
+    if (batch > 0x7fffffffull >> 3) return PLONK_HIP_ERR_INVALID_ARG;
     PassPlan pl = make_plan(log_n);
     Fr *ws = nullptr;
     if (natural) {
@@ -498,8 +660,6 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     }
     // the split scale needs the s0 = 0 pass to come last, as it does for DIF
     if (scale_upper && (!dif || !scale)) return PLONK_HIP_ERR_INVALID_ARG;
-    Fr29 sc = scale ? fr29_twiddle_from(*scale) : Fr29{};
-    Fr29 sc_up = scale_upper ? fr29_twiddle_from(*scale_upper) : Fr29{};
     const int scale_mode = scale_upper ? 2 : 1;
     if (!ctx->ntt_lds_opt_in) {
         // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS (set once per
@@ -510,10 +670,17 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         ctx->ntt_lds_opt_in = true;
     }
+    // every table first: building one may grow a buffer, which waits for the stream
+    const Tw29 *tws[6], *corrs[6];
+    for (int i = 0; i < pl.npass; i++) {
+        PLONK_TRY(get_twiddles(ctx, pl.s1[i] - pl.s0[i], inverse_tw, &tws[i]));
+        corrs[i] = nullptr;
+        if (pl.s0[i] != 0) PLONK_TRY(get_correction(ctx, pl.s0[i], pl.s1[i], inverse_tw, &corrs[i]));
+    }
     for (int q = 0; q < pl.npass; q++) {
         int i = dif ? pl.npass - 1 - q : q;
         uint32_t k = pl.s1[i] - pl.s0[i];
-        bool last = q == pl.npass - 1;
+        bool first = q == 0, last = q == pl.npass - 1;
         // small tiles: several per block so that a block has 1024 elements (128 work items)
         // tiles per block: up to 1024 elements per block in the contiguous pass (small tiles),
         // up to 2048 in a strided pass (adjacent columns: 128-byte rows from 4 columns on)
@@ -524,30 +691,44 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         const uint32_t tile_n = 1u << k;
         const size_t lds = (size_t)(9 * tile_n + (tile_n >> 5) + 1) * 4 << tpb_log;
         const unsigned threads = k + tpb_log >= 11 ? 256 : 128;
-        dim3 grid((unsigned)((n >> k) >> tpb_log), (unsigned)batch);
-        const int sm = (last && scale) ? scale_mode : 0, canon = last ? 1 : 0;
+        PassArgs a;
+        a.batch_stride = n;
+        a.log_n = log_n;
+        a.s0 = pl.s0[i];
+        a.s1 = pl.s1[i];
+        a.tpb_log = tpb_log;
+        a.batch = (uint32_t)batch;
+        a.tile_blocks = (uint32_t)((n >> k) >> tpb_log);
+        if ((size_t)a.tile_blocks * batch > 0x7fffffffull) return PLONK_HIP_ERR_INVALID_ARG;
+        a.do_scale = (last && scale && !post) ? scale_mode : 0;
+        a.canonical_out = last ? 1 : 0;
+        // a batch shares the per-element tables through one XCD's L2 when its blocks are dealt by tile
+        const Tw29 *pass_pre = first ? pre : nullptr, *pass_post = last ? post : nullptr;
+        a.xcd_map = (batch > 1 && a.tile_blocks % 8 == 0 && (corrs[i] || pass_pre || pass_post)) ? 1 : 0;
+        a.scale = (scale && !post) ? fr29_twiddle_from(*scale) : Fr29{};
+        a.scale_upper = scale_upper ? fr29_twiddle_from(*scale_upper) : Fr29{};
         // natural order: DIF = strided pass (rows stored reversed) then the s0 = 0 pass (scattered
         // store); DIT is the mirror image with the maps on the loads
-        int in_map = 0, out_map = 0;
+        a.in_map = 0;
+        a.out_map = 0;
         const Fr *src = d;
         Fr *dst = d;
         if (natural) {
             const int map = pl.s0[i] == 0 ? 2 : 1;
-            if (dif) out_map = map; else in_map = map;
+            if (dif) a.out_map = map; else a.in_map = map;
             if (pl.npass == 2) {
                 if (q == 0) dst = ws; else src = ws;
             }
         }
-#define PLONK_LAUNCH_PASS(DIFV, G)                                                                               \
-    hipLaunchKernelGGL((k_ntt_pass<DIFV, G>), grid, dim3(threads), lds, ctx->stream, src, dst, log_n, pl.s0[i],    \
-                       pl.s1[i], tpb_log, tw, n, sc, sc_up, sm, canon, in_map, out_map)
+        const dim3 grid(a.tile_blocks * (unsigned)batch);
         // (a two-stage variant, GMAX = 2, runs four waves per SIMD at the same speed)
         if (dif) {
-            PLONK_LAUNCH_PASS(true, 3);
+            hipLaunchKernelGGL((k_ntt_pass<true, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corrs[i],
+                               pass_pre, pass_post, a);
         } else {
-            PLONK_LAUNCH_PASS(false, 3);
+            hipLaunchKernelGGL((k_ntt_pass<false, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corrs[i],
+                               pass_pre, pass_post, a);
         }
-#undef PLONK_LAUNCH_PASS
     }
     return PLONK_HIP_OK;
 }
@@ -594,23 +775,37 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
     const size_t n = (size_t)1 << log_n;
     Fr ninv = fe_inv(fr_from_u64(n));
     if (coset_shift && inverse && fe_is_zero(*coset_shift)) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
-    if (!inverse && coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
+    // the coset factors ride on the first load (forward) or the last store (inverse, with 1/n);
+    // transforms of 2 or 4 points scale in a launch of their own
+    const Tw29 *pre = nullptr, *post = nullptr;
+    const bool tiny = log_n < 3;
+    if (coset_shift && !tiny) {
+        if (fe_is_zero(*coset_shift)) {
+            // f(0 * X) = f_0 everywhere: keep the constant coefficient only (no table of powers of 0)
+            PLONK_HIP_TRY(ctx, hipMemset2DAsync(d_data + 1, n * sizeof(Fr), 0, (n - 1) * sizeof(Fr), batch, ctx->stream));
+        } else if (inverse) {
+            PLONK_TRY(get_coset_table(ctx, log_n, *coset_shift, true, &post));
+        } else {
+            PLONK_TRY(get_coset_table(ctx, log_n, *coset_shift, false, &pre));
+        }
+    }
+    if (!inverse && coset_shift && tiny) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
     if (log_n >= 3 && log_n <= kMaxNaturalLog) {
         if (!inverse) {
-            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, true));
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, true, pre, nullptr));
         } else {
-            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, true));
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, true, nullptr, post));
         }
     } else if (!inverse) {
-        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr));
+        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, false, pre, nullptr));
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);
     } else {
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);
-        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv));
+        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, false, nullptr, post));
     }
-    if (inverse && coset_shift) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, fe_inv(*coset_shift)));
+    if (inverse && coset_shift && tiny) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, fe_inv(*coset_shift)));
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
@@ -726,14 +921,22 @@ int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch
     if (fe_is_zero(z_even) || fe_is_zero(z_odd)) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
     Fr inv_even = fe_inv(z_even), inv_odd = fe_inv(z_odd);
 
-    PLONK_TRY(scale_by_powers(ctx, d_f, n, batch, g));
-    // 1/Z rides on the store of the last butterfly pass
-    PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd));
     Fr ninv = fe_inv(fr_from_u64(n));
-    PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv));
-    // only the k quotient coefficients are shifted back: the upper half is zero exactly when it was zero
-    // before (every factor is a non-zero power), and that is all the divisibility test below reads
-    PLONK_TRY(scale_by_powers(ctx, d_f, k, batch, fe_inv(g), n));
+    if (log_n < 3) {
+        PLONK_TRY(scale_by_powers(ctx, d_f, n, batch, g));
+        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd));
+        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv));
+        PLONK_TRY(scale_by_powers(ctx, d_f, k, batch, fe_inv(g), n));
+    } else {
+        // g^i rides on the first load, 1/Z on the store of the last forward pass, g^-i / n on the last
+        // store of the way back (the upper half is zero exactly when it was zero before: every factor is
+        // a non-zero power, and that is all the divisibility test below reads)
+        const Tw29 *pre, *post;
+        PLONK_TRY(get_coset_table(ctx, log_n, g, false, &pre));
+        PLONK_TRY(get_coset_table(ctx, log_n, g, true, &post));
+        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd, false, pre, nullptr));
+        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv, nullptr, false, nullptr, post));
+    }
     if (d_divisible) {
         hipLaunchKernelGGL(k_set_int, dim3(cdiv(batch, 256)), dim3(256), 0, ctx->stream, d_divisible, batch, 1);
         hipLaunchKernelGGL(k_check_zero, dim3(cdiv(k, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_f, k, k, n,
