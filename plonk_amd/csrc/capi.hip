@@ -122,8 +122,10 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
         for (int i = 0; i < 33; i++) {
             buf_release(ctx->twiddle[d][i]);
             buf_release(ctx->coset_tab[d][i]);
-            for (int j = 0; j < 33; j++) buf_release(ctx->ntt_corr[d][i][j]);
         }
+    for (int kind = 0; kind < 4; kind++)
+        for (int i = 0; i < 33; i++)
+            for (int j = 0; j < 33; j++) buf_release(ctx->ntt_corr[kind][i][j]);
     for (int i = 0; i <= PH_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 2; i++) {

@@ -64,9 +64,9 @@ struct plonk_hip_ctx {
     plonk::DevBuf gen_table;
     // twiddles for the NTT: per log_n forward and inverse tables
     plonk::DevBuf twiddle[2][33];
-    // per-element factor tables of the strided passes, [inverse][s1][s0], and of coset transforms,
+    // per-element factor tables of the strided passes, [kind][s1][s0] (ntt.hip: CorrKind), and of coset transforms,
     // [inverse][log_n] (one shift cached per size and direction)
-    plonk::DevBuf ntt_corr[2][33][33];
+    plonk::DevBuf ntt_corr[4][33][33];
     plonk::DevBuf coset_tab[2][33];
     plonk::Fr coset_shift[2][33];
     bool coset_ok[2][33] = {};

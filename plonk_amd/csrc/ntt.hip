@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256) void k_twiddle29_scaled(const Fr *__restrict__
 }
 // Correction factors of a strided pass over the stages [s0, s1): out[(j << s0) | t] = w^(t * rev(j)),
 // w the primitive 2^s1-th root the lo / hi tables are powers of, rev over the s1 - s0 bits of j.
+// With `scaled` the rows j of the lower half are multiplied by f_lower and those of the upper half by
+// f_upper on top of that (a 1/n, or the two values of 1/Z on a coset, folded into the same product).
 __global__ __launch_bounds__(256) void k_correction29(const Fr *__restrict__ lo, const Fr *__restrict__ hi, uint32_t s0,
-                                                     uint32_t s1, Tw29 *__restrict__ out) {
+                                                     uint32_t s1, int scaled, Fr f_lower, Fr f_upper,
+                                                     Tw29 *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> s1) return;
     const uint32_t k = s1 - s0;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void k_correction29(const Fr *__restrict__ lo,
     const uint64_t e = (t * jr) & (((uint64_t)1 << s1) - 1);
     Fr v = lo[e & 1023];
     if (e >> 10) v = fe_mul(v, hi[e >> 10]);
+    if (scaled) v = fe_mul(v, (i >> (s1 - 1)) ? f_upper : f_lower);
     Tw29 o;
     o.v = fr29_twiddle_from(v);
     o.pad[0] = o.pad[1] = o.pad[2] = 0;
@@ -226,18 +230,27 @@ static int get_twiddles(plonk_hip_ctx *ctx, uint32_t log_n, bool inverse, const 
     return PLONK_HIP_OK;
 }
 
-// w_(2^s1)^(t * rev(j)) at (j << s0) | t for the strided pass over [s0, s1)
-static int get_correction(plonk_hip_ctx *ctx, uint32_t s0, uint32_t s1, bool inverse, const Tw29 **out) {
-    DevBuf &b = ctx->ntt_corr[inverse ? 1 : 0][s1][s0];
+// w_(2^s1)^(t * rev(j)) at (j << s0) | t for the strided pass over [s0, s1).  Kinds:
+//   kCorrForward / kCorrInverse   the plain factors for w = omega or omega^-1
+//   kCorrInverseScaled            omega^-1 factors times 2^-s1: an inverse transform whose last pass is
+//                                 this one needs no separate multiplication by 1/n
+//   kCorrForwardOverZ             omega factors times 1 / (g^k (-1)^e - 1), k = 2^(s1-1), g = 7: the values of
+//                                 1 / (X^k - 1) on the coset g * <omega>; the exponent e of the point an
+//                                 element ends up at is even exactly for the rows j of the lower half
+enum CorrKind { kCorrForward = 0, kCorrInverse = 1, kCorrInverseScaled = 2, kCorrForwardOverZ = 3 };
+static int get_correction(plonk_hip_ctx *ctx, uint32_t s0, uint32_t s1, CorrKind kind, const Fr *f_lower,
+                          const Fr *f_upper, const Tw29 **out) {
+    DevBuf &b = ctx->ntt_corr[kind][s1][s0];
     const size_t count = (size_t)1 << s1;
     if (!b.ptr) {
         Fr w = fr_root_of_unity(s1);
-        if (inverse) w = fe_inv(w);
+        if (kind == kCorrInverse || kind == kCorrInverseScaled) w = fe_inv(w);
         const Fr *lo, *hi;
         PLONK_TRY(build_two_level(ctx, w, count, &lo, &hi));
         PLONK_TRY(buf_reserve(ctx, b, count * sizeof(Tw29)));
+        const Fr one = fe_one<FrCfg>();
         hipLaunchKernelGGL(k_correction29, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, lo, hi, s0, s1,
-                           (Tw29 *)b.ptr);
+                           f_lower ? 1 : 0, f_lower ? *f_lower : one, f_upper ? *f_upper : one, (Tw29 *)b.ptr);
     }
     *out = (const Tw29 *)b.ptr;
     return PLONK_HIP_OK;
@@ -620,9 +633,13 @@ static PassPlan make_plan(uint32_t log_n) {
 // DIF then takes natural order to natural order, DIT likewise; transforms of more than one pass
 // go through the context's transform workspace (the scattering pass cannot work in place).
 static constexpr uint32_t kMaxNaturalLog = 20;
+// scale_is: what `scale` (and `scale_upper`) are known to be, which lets them be folded into a cached table:
+// kScaleInverseOfN = 2^-log_n; kScaleInverseOfZ = the two values of 1 / (X^(n/2) - 1) on the coset 7 * <omega>.
+enum ScaleIs { kScaleArbitrary = 0, kScaleInverseOfN = 1, kScaleInverseOfZ = 2 };
 static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, bool inverse_tw, bool dif,
                       const Fr *scale, const Fr *scale_upper = nullptr, bool natural = false,
-                      const Tw29 *pre = nullptr, const Tw29 *post = nullptr) {
+                      const Tw29 *pre = nullptr, const Tw29 *post = nullptr, ScaleIs scale_is = kScaleArbitrary) {
+    const bool scale_is_inverse_of_n = scale_is == kScaleInverseOfN, scale_is_inverse_of_z = scale_is == kScaleInverseOfZ;
     const size_t n = (size_t)1 << log_n;
     if (log_n <= 2) {
         if (pre || post) return PLONK_HIP_ERR_INVALID_ARG;
@@ -660,7 +677,6 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     }
     // the split scale needs the s0 = 0 pass to come last, as it does for DIF
     if (scale_upper && (!dif || !scale)) return PLONK_HIP_ERR_INVALID_ARG;
-    const int scale_mode = scale_upper ? 2 : 1;
     if (!ctx->ntt_lds_opt_in) {
         // tiles of 2^11 elements need more than the default 64 KiB of dynamic LDS (set once per
         // context, i.e. per device)
@@ -672,11 +688,31 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
     }
     // every table first: building one may grow a buffer, which waits for the stream
     const Tw29 *tws[6], *corrs[6];
+    // A constant factor on every output can ride in the correction table of the strided pass that ends
+    // at log_n instead of costing a product of its own: 1/n of an inverse transform (DIT: that pass
+    // comes last), and the two values of 1/Z of the coset quotient (DIF: which one applies is known
+    // from the row of that pass already).
+    bool scale_folded = false;
     for (int i = 0; i < pl.npass; i++) {
         PLONK_TRY(get_twiddles(ctx, pl.s1[i] - pl.s0[i], inverse_tw, &tws[i]));
         corrs[i] = nullptr;
-        if (pl.s0[i] != 0) PLONK_TRY(get_correction(ctx, pl.s0[i], pl.s1[i], inverse_tw, &corrs[i]));
+        if (pl.s0[i] == 0) continue;
+        CorrKind kind = inverse_tw ? kCorrInverse : kCorrForward;
+        const Fr *f_lower = nullptr, *f_upper = nullptr;
+        if (pl.s1[i] == log_n && scale && !post) {
+            if (!dif && inverse_tw && !scale_upper && scale_is_inverse_of_n) {
+                kind = kCorrInverseScaled;
+                f_lower = f_upper = scale;
+            } else if (dif && !inverse_tw && scale_upper && scale_is_inverse_of_z) {
+                kind = kCorrForwardOverZ;
+                f_lower = scale;
+                f_upper = scale_upper;
+            }
+            scale_folded = f_lower != nullptr;
+        }
+        PLONK_TRY(get_correction(ctx, pl.s0[i], pl.s1[i], kind, f_lower, f_upper, &corrs[i]));
     }
+    if (scale_folded) scale = scale_upper = nullptr;
     for (int q = 0; q < pl.npass; q++) {
         int i = dif ? pl.npass - 1 - q : q;
         uint32_t k = pl.s1[i] - pl.s0[i];
@@ -700,7 +736,7 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         a.batch = (uint32_t)batch;
         a.tile_blocks = (uint32_t)((n >> k) >> tpb_log);
         if ((size_t)a.tile_blocks * batch > 0x7fffffffull) return PLONK_HIP_ERR_INVALID_ARG;
-        a.do_scale = (last && scale && !post) ? scale_mode : 0;
+        a.do_scale = (last && scale && !post) ? (scale_upper ? 2 : 1) : 0;
         a.canonical_out = last ? 1 : 0;
         // a batch shares the per-element tables through one XCD's L2 when its blocks are dealt by tile
         const Tw29 *pass_pre = first ? pre : nullptr, *pass_post = last ? post : nullptr;
@@ -761,7 +797,8 @@ int ntt_butterflies(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch
     for (size_t b0 = 0; b0 < batch; b0 += 32768) {
         size_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
         if (inverse) {
-            PLONK_TRY(run_passes(ctx, d_data + b0 * n, log_n, nb, true, false, &ninv));
+            PLONK_TRY(run_passes(ctx, d_data + b0 * n, log_n, nb, true, false, &ninv, nullptr, false, nullptr, nullptr,
+                                 kScaleInverseOfN));
         } else {
             PLONK_TRY(run_passes(ctx, d_data + b0 * n, log_n, nb, false, true, nullptr));
         }
@@ -792,9 +829,12 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
     if (!inverse && coset_shift && tiny) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, *coset_shift));
     if (log_n >= 3 && log_n <= kMaxNaturalLog) {
         if (!inverse) {
-            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, true, pre, nullptr));
+            // natural order to natural order both ways: the DIT butterflies are the cheaper ones (no
+            // reduction steps between the stages), so the forward transform uses them as well
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, false, nullptr, nullptr, true, pre, nullptr));
         } else {
-            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, true, nullptr, post));
+            PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, true, nullptr, post,
+                                 kScaleInverseOfN));
         }
     } else if (!inverse) {
         PLONK_TRY(run_passes(ctx, d_data, log_n, batch, false, true, nullptr, nullptr, false, pre, nullptr));
@@ -803,7 +843,8 @@ int ntt_dev(plonk_hip_ctx *ctx, Fr *d_data, uint32_t log_n, size_t batch, bool i
     } else {
         hipLaunchKernelGGL(k_bitrev_swap, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data, log_n,
                            n);
-        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, false, nullptr, post));
+        PLONK_TRY(run_passes(ctx, d_data, log_n, batch, true, false, &ninv, nullptr, false, nullptr, post,
+                             kScaleInverseOfN));
     }
     if (inverse && coset_shift && tiny) PLONK_TRY(scale_by_powers(ctx, d_data, n, batch, fe_inv(*coset_shift)));
     PLONK_HIP_TRY(ctx, hipGetLastError());
@@ -934,7 +975,8 @@ int quotient_coset_dev(plonk_hip_ctx *ctx, Fr *d_f, uint32_t log_k, size_t batch
         const Tw29 *pre, *post;
         PLONK_TRY(get_coset_table(ctx, log_n, g, false, &pre));
         PLONK_TRY(get_coset_table(ctx, log_n, g, true, &post));
-        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd, false, pre, nullptr));
+        PLONK_TRY(run_passes(ctx, d_f, log_n, batch, false, true, &inv_even, &inv_odd, false, pre, nullptr,
+                             kScaleInverseOfZ));
         PLONK_TRY(run_passes(ctx, d_f, log_n, batch, true, false, &ninv, nullptr, false, nullptr, post));
     }
     if (d_divisible) {
