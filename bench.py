@@ -218,9 +218,6 @@ def main():
     # ranks (ranks then share devices and the 144-byte partials are staged through the host)
     backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count()
-    if world > torch.cuda.device_count():
-        # ranks share a GPU (rehearsal): keep each MSM on one stream, see plonk_hip.h
-        os.environ.setdefault("PLONK_HIP_SERIAL_TAILS", "1")
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     if world > 1:

@@ -306,12 +306,10 @@ int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeff
 /* A list of independent commitments and openings of resident polynomials in one call (the groups
  * of protocols.rs:191-195, 652-667, 761-771): task k commits to polynomial k (open[k] = 0) or opens it at
  * us[4k..4k+4) (open[k] = 1).  outs = m x 18 (commitment or proof), vs = m x 4 (f(u), zero for a
- * commitment); m <= 64.  Queued back to back: the serial tail of one multi-scalar multiplication runs
- * beside the accumulation of the next, on a second stream of the context (so do plonk_hip_kzg_commit_batch,
- * _commit_many_dev and _open_many{,_dev}).  The two streams wait for each other's events; when several
- * processes share one GPU and its hardware queues are oversubscribed such waits can stall for a long time:
- * set PLONK_HIP_SERIAL_TAILS=1 in the environment of such processes to keep every multiplication on one
- * stream.  One process per GPU, the intended deployment, is not affected. */
+ * commitment); m <= 64.  Queued back to back on the context's stream: every multi-scalar multiplication of the
+ * list stops after its bucket accumulation, and the serial tails (bucket fix-up and reduction: chains of
+ * dependent point additions that leave most of the GPU idle) of up to 16 of them then run side by side in one
+ * set of launches (so do plonk_hip_kzg_commit_batch, _commit_many_dev and _open_many{,_dev}). */
 int plonk_hip_kzg_commit_open_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns,
                                        const uint8_t *open, const uint64_t *us /* m x 4 */, size_t m,
                                        uint64_t *vs, uint64_t *outs);

@@ -16,7 +16,6 @@ int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.ptr) {
         // kernels already queued may still read the old allocation
         PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->tail_stream) PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->tail_stream));
         PLONK_HIP_TRY(ctx, hipFree(b.ptr));
         b.ptr = nullptr;
         b.bytes = 0;
@@ -110,12 +109,10 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
                       &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
                       &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b,
-                      &ctx->bucket_start2, &ctx->buckets2, &ctx->seg_part2, &ctx->big_list2,
                       &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws, &ctx->ntt3_ws};
     for (DevBuf *b : bufs) buf_release(*b);
     for (int d = 0; d < 2; d++)
@@ -128,11 +125,12 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
             for (int j = 0; j < 33; j++) buf_release(ctx->ntt_corr[kind][i][j]);
     for (int i = 0; i <= PH_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->ev_acc[i]) (void)hipEventDestroy(ctx->ev_acc[i]);
-        if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
+    for (auto &t : ctx->tail_bufs) {
+        buf_release(t.bucket_start);
+        buf_release(t.buckets);
+        buf_release(t.seg_part);
+        buf_release(t.big_list);
     }
-    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -27,6 +27,25 @@ struct MsmPlan {
 
 enum MsmPhase { PH_DIGITS = 0, PH_SORT, PH_BOUNDS, PH_ACCUM, PH_FIXUP, PH_REDUCE, PH_COUNT };
 
+// One MSM whose tail is still to run (device pointers; bucket arrays are G1Xyzz28, see g1_28.cuh).
+static constexpr int kMaxTailSlots = 16;
+struct TailDesc {
+    const uint32_t *start;      // bucket bounds
+    const void *part;           // segment partials
+    void *buckets;              // bucket sums (whole buckets already there)
+    const uint32_t *big_count;  // queue of the buckets that take a whole block
+    const uint32_t *big_list;
+    void *red;                  // row sums, column sums, bit sums of the reduction
+    void *out;                  // G1Jac result, or null: stop after the bucket sums
+    uint32_t seg_len, g_log, per_lane, group_blocks;
+};
+struct TailBatch {
+    TailDesc d[kMaxTailSlots];
+};
+struct TailSlotBufs {
+    DevBuf bucket_start, buckets, seg_part, big_list;
+};
+
 }  // namespace plonk
 
 struct plonk_hip_ctx {
@@ -45,14 +64,15 @@ struct plonk_hip_ctx {
     // MSM workspace
     plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
     plonk::DevBuf bucket_start, buckets, seg_part, big_list, red_a, red_b, red_lw, red_sum_a, red_sum_b;
-    // A batch of MSMs runs the serial tail (fix-up, reduction) of one MSM on `tail_stream` while the main
-    // stream already sorts and accumulates the next one: the buffers the tail reads exist twice
-    // (slot 0: the ones above) and events order the two streams.
-    plonk::DevBuf bucket_start2, buckets2, seg_part2, big_list2;
-    hipStream_t tail_stream = nullptr;
-    hipEvent_t ev_acc[2] = {}, ev_tail[2] = {};
-    bool tail_pending[2] = {false, false};
-    int tail_slot = 0;
+    // A batch of MSMs (several commitments / openings queued by one call) defers the serial tails: every
+    // MSM of the batch stops after its accumulation, leaving its bucket bounds, whole buckets and segment
+    // partials in a slot of its own, and ONE set of tail launches (fix-up, row / column sums, bit sums,
+    // final chain) then finishes all pending slots side by side -- the tails are chains of dependent
+    // point additions that leave most of the GPU idle, so n of them take about as long as one.
+    // Everything stays on the context's single stream.  Slot 0 is the set of buffers above.
+    plonk::TailSlotBufs tail_bufs[plonk::kMaxTailSlots - 1];
+    plonk::TailDesc pending[plonk::kMaxTailSlots];
+    int npending = 0;
     plonk::DevBuf scalars_stage, out_stage, stage_c;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
@@ -104,11 +124,11 @@ void buf_release(DevBuf &b);
 // msm.hip
 MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
 // d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
-// overlap: leave the tail of this MSM running on the tail stream; the caller calls msm_join before it
-// reads d_out or returns.
+// overlap: defer the tail of this MSM (its result is written when msm_join runs the pending tails; the
+// caller calls msm_join before it reads d_out or returns).
 int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out = nullptr,
                 bool overlap = false);
-// the main stream waits for every tail still running
+// runs the tails of all pending MSMs (one set of launches for all of them)
 int msm_join(plonk_hip_ctx *ctx);
 int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first, size_t count,
                          G1Jac *d_out);

@@ -512,13 +512,15 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *__restrict__ s
 // the bucket's partials (stride 2^g_log), then a shuffle tree joins the group.  Whole buckets
 // (written by k_accumulate in its lazy form) and empty ones pass through the same code.
 // Blocks behind them: one block per queued bucket (grid-stride over the queue).
-__global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict__ start, uint32_t nbuckets,
-                                                      uint32_t seg_len, const G1Xyzz28 *__restrict__ part,
-                                                      G1Xyzz28 *__restrict__ buckets, uint32_t g_log,
-                                                      uint32_t per_lane, uint32_t group_blocks,
-                                                      const uint32_t *__restrict__ big_count,
-                                                      const uint32_t *__restrict__ big_list) {
+__global__ __launch_bounds__(kTreeBlock) void k_fixup(TailBatch tb, uint32_t nbuckets) {
     __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    // one MSM of the batch per grid row; blocks past this MSM's lane groups all serve its queue
+    const TailDesc &d = tb.d[blockIdx.y];
+    const uint32_t *__restrict__ start = d.start;
+    const G1Xyzz28 *__restrict__ part = (const G1Xyzz28 *)d.part;
+    G1Xyzz28 *__restrict__ buckets = (G1Xyzz28 *)d.buckets;
+    const uint32_t *__restrict__ big_count = d.big_count, *__restrict__ big_list = d.big_list;
+    const uint32_t seg_len = d.seg_len, g_log = d.g_log, per_lane = d.per_lane, group_blocks = d.group_blocks;
     if (blockIdx.x >= group_blocks) {
         const uint32_t count = *big_count;
         for (uint32_t i = blockIdx.x - group_blocks; i < count; i += gridDim.x - group_blocks) {
@@ -577,10 +579,14 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(const uint32_t *__restrict
 //    with R[hi] = sum_lo B[hi*L + lo] and C[lo] = sum_hi B[hi*L + lo]: two additions per bucket,
 //    then sums over at most L or H elements, then one short Horner chain.
 // ------------------------------------------------------------------------------------------
-// blocks [0, H): row sums; blocks [H, H + L): column sums
-__global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(const G1Xyzz28 *__restrict__ B, uint32_t H, uint32_t L,
-                                                             G1Xyzz28 *__restrict__ R, G1Xyzz28 *__restrict__ C) {
+// Reduction workspace of one MSM: H row sums, L column sums, then the bit sums.
+// blocks [0, H): row sums; blocks [H, H + L): column sums; grid row = MSM of the batch
+__global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(TailBatch tb, uint32_t H, uint32_t L) {
     __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    const G1Xyzz28 *__restrict__ B = (const G1Xyzz28 *)d.buckets;
+    G1Xyzz28 *__restrict__ R = (G1Xyzz28 *)d.red, *__restrict__ C = R + H;
     const uint32_t i = blockIdx.x;
     const bool row = i < H;
     const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
@@ -591,9 +597,12 @@ __global__ __launch_bounds__(kTreeBlock) void k_row_col_sums(const G1Xyzz28 *__r
 
 // The same with 256 threads per sum and cooperative additions: for bucket arrays small enough that
 // the sums do not fill the GPU anyway.
-__global__ __launch_bounds__(256) void k_row_col_sums_coop(const G1Xyzz28 *__restrict__ B, uint32_t H, uint32_t L,
-                                                           G1Xyzz28 *__restrict__ R, G1Xyzz28 *__restrict__ C) {
+__global__ __launch_bounds__(256) void k_row_col_sums_coop(TailBatch tb, uint32_t H, uint32_t L) {
     __shared__ CoopMem mem;
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    const G1Xyzz28 *__restrict__ B = (const G1Xyzz28 *)d.buckets;
+    G1Xyzz28 *__restrict__ R = (G1Xyzz28 *)d.red, *__restrict__ C = R + H;
     const uint32_t i = blockIdx.x;
     const bool row = i < H;
     const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
@@ -603,10 +612,12 @@ __global__ __launch_bounds__(256) void k_row_col_sums_coop(const G1Xyzz28 *__res
 }
 
 // block i < lbits: T_i over C; lbits <= i < lbits + hbits: T_i over R; block lbits + hbits: T_all
-__global__ __launch_bounds__(256) void k_bit_sums(const G1Xyzz28 *__restrict__ R, uint32_t hbits,
-                                                  const G1Xyzz28 *__restrict__ C, uint32_t lbits,
-                                                  G1Xyzz28 *__restrict__ T) {
+__global__ __launch_bounds__(256) void k_bit_sums(TailBatch tb, uint32_t hbits, uint32_t lbits) {
     __shared__ CoopMem mem;
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    const G1Xyzz28 *__restrict__ R = (const G1Xyzz28 *)d.red, *__restrict__ C = R + ((size_t)1 << hbits);
+    G1Xyzz28 *__restrict__ T = (G1Xyzz28 *)d.red + ((size_t)1 << hbits) + ((size_t)1 << lbits);
     const uint32_t i = blockIdx.x;
     const bool all = i == lbits + hbits, low = all || i < lbits;
     const G1Xyzz28 *A = low ? C : R;
@@ -626,9 +637,13 @@ __global__ __launch_bounds__(256) void k_bit_sums(const G1Xyzz28 *__restrict__ R
 // For a slice [first, first + 2^sbits) of a larger bucket array (first a multiple of 2^sbits, T the
 // bit sums of the slice, T[sbits] its total) the bits of `first` stand for the whole slice:
 // T_i = T_all for a set bit i >= sbits of first, O for a clear one.
-__global__ __launch_bounds__(256) void k_finish(const G1Xyzz28 *__restrict__ T, uint32_t sbits, uint32_t nbits,
-                                                uint32_t first, G1Jac *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_finish(TailBatch tb, uint32_t sbits, uint32_t nbits, uint32_t first) {
     __shared__ CoopMem m;
+    const TailDesc &desc = tb.d[blockIdx.x];
+    if (!desc.out) return;
+    const uint32_t lbits_ = (sbits + 1) / 2, hbits_ = sbits - lbits_;
+    const G1Xyzz28 *__restrict__ T = (const G1Xyzz28 *)desc.red + ((size_t)1 << hbits_) + ((size_t)1 << lbits_);
+    G1Jac *__restrict__ out = (G1Jac *)desc.out;
     const uint32_t w = threadIdx.x >> 6, d = threadIdx.x & 63;
     const uint32_t ndig = (nbits + 2) / 3;  // at most 8: nbits <= 23
     auto term = [&](uint32_t bit) {
@@ -733,25 +748,32 @@ int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out) {
 
 size_t msm_bucket_bytes() { return sizeof(G1Xyzz28); }
 
-// S = sum_b (first + b + 1) B[b] over the 2^sbits buckets at B, as a Jacobian point at d_out;
-// `first` is a multiple of 2^sbits below 2^nbits (0 and sbits == nbits for a whole bucket array).
-static int reduce_buckets(plonk_hip_ctx *ctx, hipStream_t st, const G1Xyzz28 *B, uint32_t sbits, uint32_t nbits,
-                          uint32_t first, G1Jac *d_out) {
+// Elements of reduction workspace one MSM needs: row sums, column sums, bit sums.
+static size_t reduce_ws_elems(uint32_t sbits) {
+    const uint32_t lbits = (sbits + 1) / 2, hbits = sbits - lbits;
+    return ((size_t)1 << hbits) + ((size_t)1 << lbits) + sbits + 1;
+}
+
+// For every MSM of the batch with a result pointer: S = sum_b (first + b + 1) B[b] over its 2^sbits
+// buckets as a Jacobian point; `first` is a multiple of 2^sbits below 2^nbits (0 and sbits == nbits for a
+// whole bucket array).
+static int reduce_buckets(plonk_hip_ctx *ctx, const TailBatch &tb, uint32_t count, uint32_t sbits, uint32_t nbits,
+                          uint32_t first) {
     const uint32_t lbits = (sbits + 1) / 2, hbits = sbits - lbits;
     const uint32_t L = 1u << lbits, H = 1u << hbits;
-    PLONK_TRY(buf_reserve(ctx, ctx->red_a, ((size_t)H + L + sbits + 1) * sizeof(G1Xyzz28)));
-    G1Xyzz28 *R = (G1Xyzz28 *)ctx->red_a.ptr, *C = R + H, *T = C + L;
+    hipStream_t st = ctx->stream;
     // one sum per block: wide blocks (small depth) while they are few, one wave per sum once
     // there is a sum for every SIMD (the tree levels of a wide block are mostly idle lanes)
     const uint32_t sums = H + L;
-    const uint32_t width = sums >= 1024 ? 64u : 128u;
-    if (sums < 512) {
-        hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums), dim3(256), 0, st, B, H, L, R, C);
+    const size_t all_sums = (size_t)sums * count;
+    const uint32_t width = all_sums >= 1024 ? 64u : 128u;
+    if (all_sums < 512) {
+        hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums, count), dim3(256), 0, st, tb, H, L);
     } else {
-        hipLaunchKernelGGL(k_row_col_sums, dim3(sums), dim3(width), 0, st, B, H, L, R, C);
+        hipLaunchKernelGGL(k_row_col_sums, dim3(sums, count), dim3(width), 0, st, tb, H, L);
     }
-    hipLaunchKernelGGL(k_bit_sums, dim3(sbits + 1), dim3(256), 0, st, R, hbits, C, lbits, T);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, T, sbits, nbits, first, d_out);
+    hipLaunchKernelGGL(k_bit_sums, dim3(sbits + 1, count), dim3(256), 0, st, tb, hbits, lbits);
+    hipLaunchKernelGGL(k_finish, dim3(count), dim3(256), 0, st, tb, sbits, nbits, first);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
@@ -767,6 +789,7 @@ int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts,
     if (nparts == 0 || nparts > 1024 || count < 4 || (count & (count - 1)) || count > nb || first % count ||
         first + count > nb)
         return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_TRY(msm_join(ctx));  // the workspace below is shared with pending tails
     uint32_t sbits = 0;
     while (((size_t)1 << sbits) < count) sbits++;
     const G1Xyzz28 *B = (const G1Xyzz28 *)d_parts;
@@ -776,7 +799,12 @@ int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts,
                            (uint32_t)count, (G1Xyzz28 *)ctx->buckets.ptr);
         B = (const G1Xyzz28 *)ctx->buckets.ptr;
     }
-    return reduce_buckets(ctx, ctx->stream, B, sbits, (uint32_t)ctx->plan.c - 1, (uint32_t)first, d_out);
+    PLONK_TRY(buf_reserve(ctx, ctx->red_a, reduce_ws_elems(sbits) * sizeof(G1Xyzz28)));
+    TailBatch tb = {};
+    tb.d[0].buckets = (void *)B;
+    tb.d[0].red = ctx->red_a.ptr;
+    tb.d[0].out = d_out;
+    return reduce_buckets(ctx, tb, 1, sbits, (uint32_t)ctx->plan.c - 1, (uint32_t)first);
 }
 
 // d_out: the MSM as a Jacobian point.  With d_buckets_out set (nbuckets x sizeof(G1Xyzz28) bytes of
@@ -802,39 +830,22 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     if (seg_len >= 32) seg_len = (seg_len + kStage - 1) / kStage * kStage;  // staged pair loads need whole groups
     const size_t nseg = (total + seg_len - 1) / seg_len;
 
+    // A deferred tail (overlap) takes the next free slot; anything else first finishes what is pending
+    // and uses slot 0, so that a single MSM never waits behind a batch it does not belong to.
+    if (d_buckets_out || ctx->profile) overlap = false;
+    if (!overlap || ctx->npending == kMaxTailSlots) PLONK_TRY(msm_join(ctx));
+    const int slot = ctx->npending;
+
     size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
     PLONK_TRY(buf_reserve(ctx, ctx->keys_a, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->keys_b, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + kStage) * 4));  // staged loads read whole groups
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
-    // With `overlap` the tail (fix-up, reduction) runs on the tail stream and the caller queues the
-    // next MSM right away: what the tail reads is double-buffered, slot by slot.
-    // PLONK_HIP_SERIAL_TAILS=1 keeps everything on one stream (e.g. many processes sharing one GPU, where
-    // a stream that waits for an event of a stream the hardware has not scheduled can stall for long)
-    static const bool serial_tails = [] {
-        const char *v = getenv("PLONK_HIP_SERIAL_TAILS");
-        return v && v[0] == '1';
-    }();
-    overlap = overlap && !d_buckets_out && !ctx->profile && !serial_tails;
-    if (overlap && !ctx->tail_stream) {
-        // default priority on purpose: a high-priority stream that waits for an event of the main stream
-        // can keep that stream from being scheduled when queues of several processes share a pipe
-        PLONK_HIP_TRY(ctx, hipStreamCreate(&ctx->tail_stream));
-        for (int i = 0; i < 2; i++) {
-            PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc[i], hipEventDisableTiming));
-            PLONK_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
-        }
-    }
-    const int slot = overlap ? ctx->tail_slot : 0;
-    if (ctx->tail_pending[slot]) {  // the tail that used this slot two MSMs ago
-        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[slot], 0));
-        ctx->tail_pending[slot] = false;
-    }
-    DevBuf &b_start = slot ? ctx->bucket_start2 : ctx->bucket_start;
-    DevBuf &b_buckets = slot ? ctx->buckets2 : ctx->buckets;
-    DevBuf &b_part = slot ? ctx->seg_part2 : ctx->seg_part;
-    DevBuf &b_big = slot ? ctx->big_list2 : ctx->big_list;
+    DevBuf &b_start = slot ? ctx->tail_bufs[slot - 1].bucket_start : ctx->bucket_start;
+    DevBuf &b_buckets = slot ? ctx->tail_bufs[slot - 1].buckets : ctx->buckets;
+    DevBuf &b_part = slot ? ctx->tail_bufs[slot - 1].seg_part : ctx->seg_part;
+    DevBuf &b_big = slot ? ctx->tail_bufs[slot - 1].big_list : ctx->big_list;
     PLONK_TRY(buf_reserve(ctx, b_start, ((size_t)nb + 2) * 4));
     if (!d_buckets_out) PLONK_TRY(buf_reserve(ctx, b_buckets, (size_t)nb * sizeof(G1Xyzz28)));
     PLONK_TRY(buf_reserve(ctx, b_part, nseg * 2 * sizeof(G1Xyzz28)));
@@ -869,7 +880,6 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     const uint32_t per_lane = std::max<uint32_t>(((size_t)nb << g_log) > 65536 ? 16u : 3u,
                                                  (uint32_t)std::ceil(2.0 * typical / (1u << g_log)));
     const uint32_t group_blocks = cdiv((size_t)nb << g_log, kTreeBlock);
-    const uint32_t big_blocks = std::min<uint32_t>(nb, 1024u);
     PLONK_HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
     hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, per_lane << g_log,
                        big_count, big_list);
@@ -881,33 +891,49 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
         hipLaunchKernelGGL(k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start,
                            nb, seg_len, table, buckets, part);
     }
-    record(ctx, PH_FIXUP);
-    hipStream_t ts = st;
-    if (overlap) {
-        ts = ctx->tail_stream;
-        PLONK_HIP_TRY(ctx, hipEventRecord(ctx->ev_acc[slot], st));
-        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_acc[slot], 0));
-    }
-    hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks), dim3(kTreeBlock), 0, ts, start, nb, seg_len, part,
-                       buckets, g_log, per_lane, group_blocks, big_count, big_list);
-    record(ctx, PH_REDUCE);
-    if (!d_buckets_out) PLONK_TRY(reduce_buckets(ctx, ts, buckets, (uint32_t)pl.c - 1, (uint32_t)pl.c - 1, 0, d_out));
-    record(ctx, PH_COUNT);
-    if (overlap) {
-        PLONK_HIP_TRY(ctx, hipEventRecord(ctx->ev_tail[slot], ts));
-        ctx->tail_pending[slot] = true;
-        ctx->tail_slot ^= 1;
-    }
     PLONK_HIP_TRY(ctx, hipGetLastError());
+    TailDesc &d = ctx->pending[slot];
+    d.start = start;
+    d.part = part;
+    d.buckets = buckets;
+    d.big_count = big_count;
+    d.big_list = big_list;
+    d.red = nullptr;  // assigned when the tails run
+    d.out = d_buckets_out ? nullptr : (void *)d_out;
+    d.seg_len = seg_len;
+    d.g_log = g_log;
+    d.per_lane = per_lane;
+    d.group_blocks = group_blocks;
+    ctx->npending = slot + 1;
+    if (!overlap) PLONK_TRY(msm_join(ctx));
     return PLONK_HIP_OK;
 }
 
+// The tails of all pending MSMs: one fix-up launch and one reduction (three launches) for all of them.
 int msm_join(plonk_hip_ctx *ctx) {
-    for (int slot = 0; slot < 2; slot++) {
-        if (!ctx->tail_pending[slot]) continue;
-        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[slot], 0));
-        ctx->tail_pending[slot] = false;
+    const uint32_t count = (uint32_t)ctx->npending;
+    if (count == 0) return PLONK_HIP_OK;
+    ctx->npending = 0;  // whatever happens below, the slots are free again
+    const MsmPlan &pl = ctx->plan;
+    const uint32_t nb = pl.nbuckets, sbits = (uint32_t)pl.c - 1;
+    const size_t ws = reduce_ws_elems(sbits);
+    PLONK_TRY(buf_reserve(ctx, ctx->red_a, ws * count * sizeof(G1Xyzz28)));
+    TailBatch tb = {};
+    uint32_t group_blocks = 0;
+    bool any_out = false;
+    for (uint32_t i = 0; i < count; i++) {
+        tb.d[i] = ctx->pending[i];
+        tb.d[i].red = (G1Xyzz28 *)ctx->red_a.ptr + ws * i;
+        group_blocks = std::max(group_blocks, tb.d[i].group_blocks);
+        any_out = any_out || tb.d[i].out;
     }
+    const uint32_t big_blocks = std::min<uint32_t>(nb, 1024u);
+    record(ctx, PH_FIXUP);
+    hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks, count), dim3(kTreeBlock), 0, ctx->stream, tb, nb);
+    record(ctx, PH_REDUCE);
+    if (any_out) PLONK_TRY(reduce_buckets(ctx, tb, count, sbits, sbits, 0));
+    record(ctx, PH_COUNT);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
 

@@ -16,7 +16,6 @@ pytestmark = pytest.mark.gpu
 def _worker(rank, world, port, log_n, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["PLONK_HIP_SERIAL_TAILS"] = "1"  # the ranks share one GPU here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import plonk_amd
     from plonk_amd import sharding
@@ -71,7 +70,6 @@ def test_two_ranks_both_exchanges(tmp_path, log_n):
 def _prover_worker(rank, world, port, log_gates, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["PLONK_HIP_SERIAL_TAILS"] = "1"  # the ranks share one GPU here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import plonk_amd
     from plonk_amd import prover as pv
