@@ -160,6 +160,11 @@ int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs /* n x 4 */, s
 int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
                             uint64_t *vs, uint64_t *proofs);
 
+/* GPU time of whatever is enqueued on the context's stream between the two calls (HIP events on that stream;
+ * _stop waits for the work to finish).  For measurement harnesses: a framework's own events only see the
+ * framework's stream. */
+int plonk_hip_timer_start(plonk_hip_ctx *ctx);
+int plonk_hip_timer_stop(plonk_hip_ctx *ctx, float *ms);
 /* Per-phase GPU time (ms, HIP events on the context's stream) of the most recent MSM run by
  * this context; valid after plonk_hip_profile(ctx, 1).  Phase names from
  * plonk_hip_msm_phase_name(i), i < PLONK_HIP_MSM_PHASES. */

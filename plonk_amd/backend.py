@@ -110,6 +110,15 @@ class Backend:
     def profile(self, enable=True):
         self._check(self._lib.plonk_hip_profile(self._ctx, 1 if enable else 0))
 
+    def timer_start(self):
+        self._check(self._lib.plonk_hip_timer_start(self._ctx))
+
+    def timer_stop(self):
+        """Milliseconds of GPU time since timer_start (HIP events on the library's stream); waits."""
+        ms = ctypes.c_float()
+        self._check(self._lib.plonk_hip_timer_stop(self._ctx, ctypes.byref(ms)))
+        return float(ms.value)
+
     def msm_phase_ms(self):
         ms = (ctypes.c_float * 6)()
         self._check(self._lib.plonk_hip_msm_phase_ms(self._ctx, ms))

@@ -125,6 +125,8 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
             for (int j = 0; j < 33; j++) buf_release(ctx->ntt_corr[kind][i][j]);
     for (int i = 0; i <= PH_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 2; i++)
+        if (ctx->timer_ev[i]) (void)hipEventDestroy(ctx->timer_ev[i]);
     for (auto &t : ctx->tail_bufs) {
         buf_release(t.bucket_start);
         buf_release(t.buckets);
@@ -418,6 +420,23 @@ int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *
     PLONK_ENTER(ctx);
     if (!bytes_per_second) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_gather_rate(ctx, table_bytes, bytes_per_second);
+}
+
+int plonk_hip_timer_start(plonk_hip_ctx *ctx) {
+    PLONK_ENTER(ctx);
+    for (int i = 0; i < 2; i++)
+        if (!ctx->timer_ev[i]) PLONK_HIP_TRY(ctx, hipEventCreate(&ctx->timer_ev[i]));
+    PLONK_HIP_TRY(ctx, hipEventRecord(ctx->timer_ev[0], ctx->stream));
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_timer_stop(plonk_hip_ctx *ctx, float *ms) {
+    PLONK_ENTER(ctx);
+    if (!ms || !ctx->timer_ev[0] || !ctx->timer_ev[1]) return PLONK_HIP_ERR_INVALID_ARG;
+    PLONK_HIP_TRY(ctx, hipEventRecord(ctx->timer_ev[1], ctx->stream));
+    PLONK_HIP_TRY(ctx, hipEventSynchronize(ctx->timer_ev[1]));
+    PLONK_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->timer_ev[0], ctx->timer_ev[1]));
+    return PLONK_HIP_OK;
 }
 
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable) {

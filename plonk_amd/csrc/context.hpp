@@ -95,6 +95,8 @@ struct plonk_hip_ctx {
     // this device's copy of the library's static scratch array (capi.hip), resolved at creation
     void *static_scratch = nullptr;
 
+    hipEvent_t timer_ev[2] = {};  // plonk_hip_timer_start / _stop
+
     bool profile = false;
     hipEvent_t ev[plonk::PH_COUNT + 1] = {};
     float phase_ms[plonk::PH_COUNT] = {};

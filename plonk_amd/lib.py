@@ -45,6 +45,8 @@ SIGNATURES = {
     "plonk_hip_kzg_open_many": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p]),
     "plonk_hip_profile": (ctypes.c_int, [c_ctx, ctypes.c_int]),
+    "plonk_hip_timer_start": (ctypes.c_int, [c_ctx]),
+    "plonk_hip_timer_stop": (ctypes.c_int, [c_ctx, c_floatp]),
     "plonk_hip_msm_phase_ms": (ctypes.c_int, [c_ctx, c_floatp]),
     "plonk_hip_msm_phase_name": (ctypes.c_char_p, [ctypes.c_int]),
     "plonk_hip_bench_mad_rate": (ctypes.c_int, [c_ctx, ctypes.POINTER(ctypes.c_double)]),
@@ -66,7 +68,7 @@ SIGNATURES = {
     "plonk_hip_fr_quotient_coset": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_uint32, ctypes.c_size_t, c_u64p, c_intp]),
     "plonk_hip_fr_quotient_coset_dev": (
-        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, c_intp]),
+        ctypes.c_int, [c_ctx, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_hip_srs_load_compressed": (
         ctypes.c_int, [c_ctx, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_hip_g1_decompress": (

@@ -16,6 +16,38 @@ import torch.distributed as dist
 G1_LIMBS = 18
 
 
+def polynomials_of_rank(batch, world, rank):
+    """Sharing a batch of independent polynomials (transforms, quotients) by polynomial: polynomial b
+    belongs to rank b mod world; no collective is needed on the data path."""
+    return [b for b in range(batch) if b % world == rank]
+
+
+# The library works on its own HIP stream, torch's collectives on torch's current stream: the two are
+# ordered by events, the host does not wait in between.
+_external = {}
+
+
+def _library_stream(be):
+    key = (be.device, be.stream)
+    if key not in _external:
+        _external[key] = torch.cuda.ExternalStream(be.stream, device=torch.device("cuda", be.device))
+    return _external[key]
+
+
+def library_then_torch(be):
+    """What is queued on torch's current stream from here on runs after the library's queued work."""
+    ev = torch.cuda.Event()
+    ev.record(_library_stream(be))
+    torch.cuda.current_stream().wait_event(ev)
+
+
+def torch_then_library(be):
+    """What the library queues from here on runs after the work already on torch's current stream."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _library_stream(be).wait_event(ev)
+
+
 def shard_range(n_total, world, rank):
     """Contiguous range of rank: (first, count); the first n_total % world ranks get one more."""
     base, extra = divmod(n_total, world)
@@ -47,10 +79,10 @@ def commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt, group=N
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_pt
-    be.sync()  # the collective runs on torch's stream
+    library_then_torch(be)  # the collective runs on torch's stream
     gather_partials(local_pt, gathered, group)
-    torch.cuda.current_stream().synchronize()
     if dist.get_rank(group) == 0:
+        torch_then_library(be)
         be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
     return total_pt
 
@@ -90,14 +122,14 @@ def commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathere
     nbuckets, _ = be.msm_bucket_layout()
     first, count = bucket_slice(nbuckets, world, rank)
     be.msm_buckets_dev(d_scalars, n_local, send.data_ptr())
-    be.sync()  # the collectives run on torch's stream
+    library_then_torch(be)  # the collectives run on torch's stream
     exchange_bucket_slices(send, recv, group)
-    torch.cuda.current_stream().synchronize()
+    torch_then_library(be)
     be.msm_reduce_bucket_slice_dev(recv.data_ptr(), world, first, count, local_pt.data_ptr())
-    be.sync()
+    library_then_torch(be)
     gather_partials(local_pt, gathered, group)
-    torch.cuda.current_stream().synchronize()
     if rank == 0:
+        torch_then_library(be)
         be.g1_sum_dev(gathered.data_ptr(), world, total_pt.data_ptr())
     return total_pt
 

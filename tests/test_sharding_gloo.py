@@ -153,3 +153,44 @@ def test_task_exchange_returns_every_rank_its_rows(tmp_path, world):
     out = tmp_path / "result.txt"
     mp.spawn(_task_worker, args=(world, port, str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+def _poly_worker(rank, world, port, batch, log_n, out_path):
+    """A batch of transforms shared by polynomial: each rank transforms its own polynomials (the oracle
+    stands in for plonk_hip_fr_ntt_dev), nothing is exchanged on the data path; the results are only
+    collected here to check that the ranks' shares make up the whole batch exactly once."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1 << log_n
+    rnd = random.Random(5)
+    polys = [c.fr_to_mont([rnd.randrange(o.R) for _ in range(n)]) for _ in range(batch)]
+    mine = sharding.polynomials_of_rank(batch, world, rank)
+    done = {b: c.fr_ntt(polys[b]) for b in mine}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, {b: v.tolist() for b, v in done.items()})
+    if rank == 0:
+        seen = {}
+        ok = True
+        for share in everyone:
+            for b, v in share.items():
+                ok = ok and b not in seen
+                seen[b] = np.array(v, dtype=np.uint64)
+        ok = ok and sorted(seen) == list(range(batch))
+        ok = ok and all(np.array_equal(seen[b], c.fr_ntt(polys[b])) for b in range(batch))
+        with open(out_path, "w") as fh:
+            fh.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch", [(2, 16), (3, 16), (2, 1)])
+def test_batch_of_transforms_shared_by_polynomial(tmp_path, world, batch):
+    c.build()
+    assert sorted(b for r in range(world) for b in sharding.polynomials_of_rank(batch, world, r)) == list(range(batch))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "result.txt"
+    mp.spawn(_poly_worker, args=(world, port, batch, 5, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
