@@ -122,7 +122,7 @@ def cpu_baseline(be, n_local, sample_log, threads, log_n_total):
     return out
 
 
-def cpu_baseline_ntt(threads, lagrange_log=11, ntt_log=20):
+def cpu_baseline_ntt(threads, lagrange_log=12, ntt_log=20):
     """What the reference does where the GPU path runs a transform: Lagrange interpolation
     (plonk/src/common/polynomials.rs:14-58, quadratic) restated in C, timed at a bounded size, and the
     oracle's radix-2 transform at the benchmark's size as the same-algorithm-class figure."""
@@ -130,7 +130,7 @@ def cpu_baseline_ntt(threads, lagrange_log=11, ntt_log=20):
 
     c.build()
     m = 1 << lagrange_log
-    w = c.root_of_unity(lagrange_log)
+    w = int(c.fr_from_mont(c.root_of_unity(lagrange_log).reshape(1, 4))[0])
     xs = [1]
     for _ in range(m - 1):
         xs.append(xs[-1] * w % FR_MODULUS)
@@ -538,7 +538,8 @@ def main():
     if world == 1:
         f_tau = be.fr_eval(scalars, tau)
         want = be.kzg_commit(np.ascontiguousarray(f_tau).reshape(1, 4))
-        got = total_pt.cpu().numpy().view(np.uint64)
+        be.sync()
+        got = local_pt.cpu().numpy().view(np.uint64)  # one rank: the local result is the commitment
         enc = be.g1_compress(np.stack([np.asarray(want).reshape(18), got.reshape(18)]))
         self_check = bool(enc[0] == enc[1])
 

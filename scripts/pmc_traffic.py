@@ -1,9 +1,13 @@
-"""HBM bytes per launch / per step from the FETCH_SIZE and WRITE_SIZE passes of scripts/profile.sh, as the
-JSON record bench.py reads from profiles/traffic.json.
-usage: python scripts/pmc_traffic.py TAG COMMIT   (reads gpurun_out/prof_TAG_{msm,ntt,quo}_{fetch,write})
+"""HBM bytes per launch / per step from the counter passes of scripts/profile.sh, as the JSON record
+bench.py reads from profiles/traffic.json.
+usage: python scripts/pmc_traffic.py TAG COMMIT   (reads gpurun_out/prof_TAG_{msm,ntt,quo}_{fetch,write,rdsz})
 
-gfx950: FETCH_SIZE (KB) counts 128-byte requests as 64 bytes, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE (KB)
-is exact for wide streaming stores."""
+Reads: gfx950's FETCH_SIZE (KB) tallies a 128-byte request as 64 bytes, so for wide streaming reads the
+bytes are 2 x FETCH_SIZE; kernels that read 64-byte rows (the strided transform passes) are counted
+exactly by FETCH_SIZE itself.  The size-resolved request counters settle it per kernel:
+    read bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B.
+Both figures are recorded; `bytes` uses the size-resolved one.  Writes: WRITE_SIZE (KB), exact for wide
+streaming stores."""
 import csv
 import glob
 import json
@@ -14,42 +18,53 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def per_dispatch(directory, counter):
-    out = defaultdict(float)
-    names = {}
+def per_dispatch(directory, counters):
+    """{dispatch: {counter: value}}, {dispatch: (kernel name, grid size)}"""
+    out = defaultdict(lambda: defaultdict(float))
+    meta = {}
     for path in glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter:
+                if row["Counter_Name"] not in counters:
                     continue
-                out[row["Dispatch_Id"]] += float(row["Counter_Value"])
-                names[row["Dispatch_Id"]] = row["Kernel_Name"]
-    return out, names
+                out[row["Dispatch_Id"]][row["Counter_Name"]] += float(row["Counter_Value"])
+                meta[row["Dispatch_Id"]] = (row["Kernel_Name"], int(row["Grid_Size"]))
+    return out, meta
 
 
-def kernel_bytes(tag, leg, needle):
-    """(launches, total bytes) of the kernels whose name contains `needle`."""
+def kernel_bytes(tag, leg, needle, min_grid=0):
+    """Launches of the kernels whose name contains `needle` (grid of at least min_grid work items): count, total
+    bytes by the size-resolved read counters + WRITE_SIZE, total bytes by 2 x FETCH_SIZE + WRITE_SIZE."""
     base = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, leg))
-    fetch, names = per_dispatch(base + "_fetch", "FETCH_SIZE")
-    write, wnames = per_dispatch(base + "_write", "WRITE_SIZE")
-    rd = [v for k, v in fetch.items() if needle in names[k]]
-    wr = [v for k, v in write.items() if needle in wnames[k]]
-    if not rd or len(rd) != len(wr):
-        raise SystemExit("no matching launches of %s in %s (%d reads, %d writes)" % (needle, base, len(rd), len(wr)))
-    return len(rd), (2 * sum(rd) + sum(wr)) * 1024
+
+    def pick(suffix, counters):
+        vals, meta = per_dispatch(base + suffix, counters)
+        return [vals[k] for k in sorted(vals, key=int) if needle in meta[k][0] and meta[k][1] >= min_grid]
+
+    fetch = pick("_fetch", {"FETCH_SIZE"})
+    write = pick("_write", {"WRITE_SIZE"})
+    sized = pick("_rdsz", {"TCC_EA0_RDREQ_128B", "TCC_EA0_RDREQ_64B", "TCC_EA0_RDREQ_32B"})
+    if not fetch or len(fetch) != len(write) or len(sized) != len(write):
+        raise SystemExit("launch counts of %s differ in %s: %d / %d / %d" % (needle, base, len(fetch), len(write), len(sized)))
+    wr = sum(v["WRITE_SIZE"] for v in write) * 1024
+    rd_sized = sum(128 * v["TCC_EA0_RDREQ_128B"] + 64 * v["TCC_EA0_RDREQ_64B"] + 32 * v["TCC_EA0_RDREQ_32B"] for v in sized)
+    rd_fetch2 = sum(v["FETCH_SIZE"] for v in fetch) * 2 * 1024
+    return len(write), rd_sized + wr, rd_fetch2 + wr, rd_sized, wr
 
 
 def main():
     tag, commit = sys.argv[1], sys.argv[2]
     entries = {}
-    n, total = kernel_bytes(tag, "msm", "k_accumulate")
+    n, total, total_f2, rd, wr = kernel_bytes(tag, "msm", "k_accumulate", min_grid=1 << 16)
     entries["msm_2^24_x1"] = {"k_accumulate": {
-        "bytes": int(total / n), "what": "average over %d launches of one 2^24-point commitment" % n}}
-    # bench.py --workload ntt / quotient --steps 3 --warmup 1: four steps, two passes per transform
+        "bytes": int(total / n), "bytes_by_2x_fetch_size": int(total_f2 / n), "read_bytes": int(rd / n),
+        "write_bytes": int(wr / n), "what": "average over %d launches of one 2^24-point commitment" % n}}
+    # bench.py --workload ntt / quotient --steps 3 --warmup 1: four steps
     for leg, key, steps in (("ntt", "ntt_16x2^20", 4), ("quo", "quotient_16x2^20", 4)):
-        n, total = kernel_bytes(tag, leg, "k_ntt_pass")
+        n, total, total_f2, rd, wr = kernel_bytes(tag, leg, "k_ntt_pass")
         entries[key] = {"k_ntt_pass": {
-            "bytes": int(total / steps),
+            "bytes": int(total / steps), "bytes_by_2x_fetch_size": int(total_f2 / steps), "read_bytes": int(rd / steps),
+            "write_bytes": int(wr / steps),
             "what": "all %d pass launches of %d steps, per step (16 polynomials)" % (n, steps)}}
     json.dump({"commit": commit, "tag": tag, "entries": entries}, sys.stdout, indent=1)
     print()

@@ -16,6 +16,10 @@ QUO="$ROOT/bench.py --workload quotient --steps 3 --warmup 1"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS GRBM_GUI_ACTIVE GRBM_COUNT"
 
+# read requests by size: FETCH_SIZE tallies a 128-byte request as 64 bytes, which suits wide streaming reads
+# (double it) but not kernels that read 64-byte rows; the size-resolved counts give the bytes either way
+RDSZ="TCC_EA0_RDREQ_128B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_32B TCC_EA0_RDREQ"
+
 pass() {  # name, counters, command...
     local name=$1 counters=$2
     shift 2
@@ -30,17 +34,20 @@ pass msm_sq1 "$SQ1" $MSM
 pass msm_sq2 "$SQ2" $MSM
 pass msm_fetch FETCH_SIZE $MSM
 pass msm_write WRITE_SIZE $MSM
+pass msm_rdsz "$RDSZ" $MSM
 pass ntt_sq1 "$SQ1" $NTT
 pass ntt_sq2 "$SQ2" $NTT
 pass ntt_fetch FETCH_SIZE $NTT
 pass ntt_write WRITE_SIZE $NTT
+pass ntt_rdsz "$RDSZ" $NTT
 pass quo_fetch FETCH_SIZE $QUO
 pass quo_write WRITE_SIZE $QUO
+pass quo_rdsz "$RDSZ" $QUO
 cd $ROOT
 python3 scripts/pmc_traffic.py $TAG $COMMIT > $OUT/traffic_$TAG.json || exit 2
 python3 scripts/summarize_pmc.py $OUT/pmc_${TAG}_msm.csv $OUT/prof_${TAG}_msm_sq1 $OUT/prof_${TAG}_msm_sq2 \
-    $OUT/prof_${TAG}_msm_fetch $OUT/prof_${TAG}_msm_write
+    $OUT/prof_${TAG}_msm_fetch $OUT/prof_${TAG}_msm_write $OUT/prof_${TAG}_msm_rdsz
 python3 scripts/summarize_pmc.py $OUT/pmc_${TAG}_ntt.csv $OUT/prof_${TAG}_ntt_sq1 $OUT/prof_${TAG}_ntt_sq2 \
-    $OUT/prof_${TAG}_ntt_fetch $OUT/prof_${TAG}_ntt_write
-python3 scripts/summarize_pmc.py $OUT/pmc_${TAG}_quotient.csv $OUT/prof_${TAG}_quo_fetch $OUT/prof_${TAG}_quo_write
+    $OUT/prof_${TAG}_ntt_fetch $OUT/prof_${TAG}_ntt_write $OUT/prof_${TAG}_ntt_rdsz
+python3 scripts/summarize_pmc.py $OUT/pmc_${TAG}_quotient.csv $OUT/prof_${TAG}_quo_fetch $OUT/prof_${TAG}_quo_write $OUT/prof_${TAG}_quo_rdsz
 echo done
