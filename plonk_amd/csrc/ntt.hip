@@ -415,6 +415,7 @@ struct PassArgs {
     uint32_t log_n, s0, s1, tpb_log;
     uint32_t batch, tile_blocks;  // vectors in this launch; blocks per vector
     int do_scale, canonical_out, in_map, out_map, xcd_map;
+    uint32_t xcd_group_log;  // with xcd_map: 2^xcd_group_log neighbouring tile blocks stay on one XCD
     Fr29 scale, scale_upper;
 };
 
@@ -430,8 +431,11 @@ struct PassArgs {
 // `scale` (w * 2^261 form) multiplies every output when do_scale is 1 and post is null; with do_scale 2
 // (only on the pass with s0 = 0) the upper half of each vector takes `scale_upper`.
 // Grid: tile_blocks * batch blocks.  With xcd_map the block index is read as (slot, xcd) = (L / 8,
-// L % 8), slot = group * batch + vector, and the block works on tile block 8 * group + xcd: blocks that
-// the hardware deals to one XCD (L % 8 equal) and that follow each other share their table rows.
+// L % 8), slot = (group * batch + vector) * G + g, and the block works on tile block (8 * group + xcd) * G + g:
+// blocks that the hardware deals to one XCD (L % 8 equal) and that follow each other then share their
+// table rows (the same tile block of every vector) and their memory lines (G neighbouring tile blocks:
+// a strided pass touches rows of 32 bytes per column of the block, and two blocks that split a 128-byte
+// line between them would each fetch all of it if they sat on XCDs with separate L2s).
 template <bool DIF, int GMAX>
 __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *src, Fr *dst, const Tw29 *__restrict__ tw,
                                                   const Tw29 *__restrict__ corr, const Tw29 *__restrict__ pre,
@@ -444,9 +448,9 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
     const uint32_t block_elems = tile_n << tpb_log;
     uint32_t tile_block, vec_index;
     if (a.xcd_map) {
-        const uint32_t slot = blockIdx.x >> 3;
-        tile_block = (slot / a.batch) * 8 + (blockIdx.x & 7);
-        vec_index = slot % a.batch;
+        const uint32_t slot = blockIdx.x >> 3, rest = slot >> a.xcd_group_log;
+        tile_block = ((((rest / a.batch) << 3) | (blockIdx.x & 7)) << a.xcd_group_log) | (slot & ((1u << a.xcd_group_log) - 1));
+        vec_index = rest % a.batch;
     } else {
         tile_block = blockIdx.x % a.tile_blocks;
         vec_index = blockIdx.x / a.tile_blocks;
@@ -740,7 +744,8 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         a.canonical_out = last ? 1 : 0;
         // a batch shares the per-element tables through one XCD's L2 when its blocks are dealt by tile
         const Tw29 *pass_pre = first ? pre : nullptr, *pass_post = last ? post : nullptr;
-        a.xcd_map = (batch > 1 && a.tile_blocks % 8 == 0 && (corrs[i] || pass_pre || pass_post)) ? 1 : 0;
+        a.xcd_map = 0;
+        a.xcd_group_log = 0;
         a.scale = (scale && !post) ? fr29_twiddle_from(*scale) : Fr29{};
         a.scale_upper = scale_upper ? fr29_twiddle_from(*scale_upper) : Fr29{};
         // natural order: DIF = strided pass (rows stored reversed) then the s0 = 0 pass (scattered
@@ -755,6 +760,16 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
             if (pl.npass == 2) {
                 if (q == 0) dst = ws; else src = ws;
             }
+        }
+        // rows of a strided or scattered side are 32 bytes per column of the block: neighbours that
+        // complete a 128-byte line go to the same XCD
+        const bool rows = pl.s0[i] != 0 || a.in_map == 2 || a.out_map == 2;
+        uint32_t group_log = 0;
+        while (rows && (32u << (tpb_log + group_log)) < 128u) group_log++;
+        const bool tables = batch > 1 && (corrs[i] || pass_pre || pass_post);
+        if ((group_log || tables) && a.tile_blocks % (8u << group_log) == 0) {
+            a.xcd_map = 1;
+            a.xcd_group_log = group_log;
         }
         const dim3 grid(a.tile_blocks * (unsigned)batch);
         // (a two-stage variant, GMAX = 2, runs four waves per SIMD at the same speed)
