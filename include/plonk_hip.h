@@ -352,6 +352,37 @@ int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void 
 int plonk_hip_fr_ratio_prefix_product_dev_noalloc(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n,
                                                   int *d_zero_flag);
 
+/* ----------------------------------------------------------------------------------------
+ * Several GPUs behind one handle (one process)
+ * --------------------------------------------------------------------------------------
+ * `kzg_commit(&gp, &f)` and `kzg_evaluate(&gp, &f, u)` (kzg.rs:48-88) for a `GlobalParameters` too large or a
+ * commitment too slow for one GPU: the SRS is split by point range over `n_devices` sub-contexts (devices[g]
+ * may repeat a device), each device receives its coefficient slice over its own PCIe link, runs the whole local
+ * multi-scalar multiplication and sends its 144-byte partial to the first device (peer copy, xGMI inside a
+ * node), which adds the partials up.  For an opening the suffix scan of kzg.rs:65-76 runs slice by slice with
+ * the carries chained on the host.  Same data formats, error codes and blocking semantics as the single-GPU
+ * entry points; a handle may be used from any thread (calls are serialised).  Every device holds at least one
+ * SRS point (n >= n_devices). */
+typedef struct plonk_hip_multi plonk_hip_multi;
+int plonk_hip_multi_create(const int *devices, int n_devices, plonk_hip_multi **out);
+void plonk_hip_multi_destroy(plonk_hip_multi *m);
+const char *plonk_hip_multi_last_error(plonk_hip_multi *m);
+int plonk_hip_multi_device_count(plonk_hip_multi *m);
+int plonk_hip_multi_set_window_bits(plonk_hip_multi *m, int c);
+/* `GlobalParameters.tau_powers_g1` (kzg.rs:17-21) / `kzg_setup` (kzg.rs:24-45), as the single-GPU forms. */
+int plonk_hip_multi_srs_load_projective(plonk_hip_multi *m, const uint64_t *pts /* n x 18 */, size_t n);
+int plonk_hip_multi_kzg_setup(plonk_hip_multi *m, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
+int plonk_hip_multi_srs_size(plonk_hip_multi *m, size_t *n);
+/* SRS range [first, first + count) held by sub-context `index`. */
+int plonk_hip_multi_srs_range(plonk_hip_multi *m, int index, size_t *first, size_t *count);
+/* `kzg_commit` (kzg.rs:48-60), `kzg_evaluate` (kzg.rs:63-88) and the batched commitments
+ * (protocols.rs:191-195, 652-653, 761). */
+int plonk_hip_multi_kzg_commit(plonk_hip_multi *m, const uint64_t *coeffs /* n x 4 */, size_t n, uint64_t out[18]);
+int plonk_hip_multi_kzg_commit_batch(plonk_hip_multi *m, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
+                                     uint64_t *outs);
+int plonk_hip_multi_kzg_open(plonk_hip_multi *m, const uint64_t *coeffs /* n x 4 */, size_t n, const uint64_t u[4],
+                             uint64_t v[4], uint64_t proof[18]);
+
 #ifdef __cplusplus
 }
 #endif

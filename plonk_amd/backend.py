@@ -517,3 +517,83 @@ class Backend:
 
     def quotient_coset_dev(self, dptr, log_k, batch, d_flags=None):
         self._check(self._lib.plonk_hip_fr_quotient_coset_dev(self._ctx, dptr, log_k, batch, d_flags))
+
+
+class MultiBackend:
+    """Several GPUs behind one handle in one process (plonk_hip_multi_*): the SRS split by point range,
+    `kzg_commit` / `kzg_evaluate` sharded inside the library.  devices: device ordinals, one sub-context
+    each (an ordinal may repeat)."""
+
+    def __init__(self, devices, window_bits=0):
+        self._lib = _l.load_library()
+        self._h = _l.c_ctx()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = self._lib.plonk_hip_multi_create(arr, len(devices), ctypes.byref(self._h))
+        if rc != 0:
+            raise PlonkHipError(rc, self._lib.plonk_hip_strerror(rc).decode())
+        if window_bits:
+            self._check(self._lib.plonk_hip_multi_set_window_bits(self._h, window_bits))
+
+    def close(self):
+        if self._h:
+            self._lib.plonk_hip_multi_destroy(self._h)
+            self._h = _l.c_ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        text = self._lib.plonk_hip_strerror(rc).decode()
+        detail = self._lib.plonk_hip_multi_last_error(self._h).decode()
+        if detail and rc in (-6, -7):
+            text += " (" + detail + ")"
+        if rc == ERR_SRS_TOO_SHORT:
+            raise CommitError(rc, text)
+        if rc in (ERR_EMPTY_POLY, ERR_ZERO_DENOMINATOR, ERR_INVALID_POINT):
+            raise ReferencePanic(rc, text)
+        raise PlonkHipError(rc, text)
+
+    def device_count(self):
+        return self._lib.plonk_hip_multi_device_count(self._h)
+
+    def srs_range(self, index):
+        first, count = ctypes.c_size_t(), ctypes.c_size_t()
+        self._check(self._lib.plonk_hip_multi_srs_range(self._h, index, ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
+
+    def srs_load_projective(self, pts):
+        pts = _fr(pts, 18)
+        self._check(self._lib.plonk_hip_multi_srs_load_projective(self._h, _u64(pts), pts.shape[0]))
+
+    def kzg_setup(self, tau, degree, want_points=True):
+        tau = _fr(tau).reshape(4)
+        out = np.empty((degree + 1, 18), dtype=np.uint64) if want_points else None
+        self._check(self._lib.plonk_hip_multi_kzg_setup(self._h, _u64(tau), degree, _u64(out) if want_points else None))
+        return out
+
+    def kzg_commit(self, coeffs):
+        coeffs = _fr(coeffs)
+        out = np.empty(18, dtype=np.uint64)
+        self._check(self._lib.plonk_hip_multi_kzg_commit(self._h, _u64(coeffs), coeffs.shape[0], _u64(out)))
+        return out
+
+    def kzg_commit_batch(self, polys):
+        polys = [_fr(p) for p in polys]
+        ptrs = (_l.c_u64p * len(polys))(*[_u64(p) for p in polys])
+        ns = (ctypes.c_size_t * len(polys))(*[p.shape[0] for p in polys])
+        outs = np.empty((len(polys), 18), dtype=np.uint64)
+        self._check(self._lib.plonk_hip_multi_kzg_commit_batch(self._h, ptrs, ns, len(polys), _u64(outs)))
+        return outs
+
+    def kzg_evaluate(self, coeffs, u):
+        coeffs = _fr(coeffs)
+        u = _fr(u).reshape(4)
+        v = np.empty(4, dtype=np.uint64)
+        proof = np.empty(18, dtype=np.uint64)
+        self._check(self._lib.plonk_hip_multi_kzg_open(self._h, _u64(coeffs), coeffs.shape[0], _u64(u), _u64(v), _u64(proof)))
+        return v, proof

@@ -126,6 +126,19 @@ SIGNATURES = {
     "plonk_hip_fr_div_by_roots": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_interpolate": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_multi_create": (ctypes.c_int, [c_intp, ctypes.c_int, ctypes.POINTER(c_ctx)]),
+    "plonk_hip_multi_destroy": (None, [c_ctx]),
+    "plonk_hip_multi_last_error": (ctypes.c_char_p, [c_ctx]),
+    "plonk_hip_multi_device_count": (ctypes.c_int, [c_ctx]),
+    "plonk_hip_multi_set_window_bits": (ctypes.c_int, [c_ctx, ctypes.c_int]),
+    "plonk_hip_multi_srs_load_projective": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t]),
+    "plonk_hip_multi_kzg_setup": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_multi_srs_size": (ctypes.c_int, [c_ctx, c_sizep]),
+    "plonk_hip_multi_srs_range": (ctypes.c_int, [c_ctx, ctypes.c_int, c_sizep, c_sizep]),
+    "plonk_hip_multi_kzg_commit": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_multi_kzg_commit_batch": (
+        ctypes.c_int, [c_ctx, ctypes.POINTER(c_u64p), c_sizep, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_multi_kzg_open": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, c_u64p, c_u64p]),
 }
 
 _lib = None
