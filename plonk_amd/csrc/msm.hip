@@ -426,8 +426,9 @@ __device__ __forceinline__ bool coop_is_identity(const CoopMem &m, int base, uin
 
 // A[s] += (b_self ? A : B)[s + boff] for the slots s < nact (s + boff < 64).  Called by all 256
 // threads of the block after a barrier that made the operands visible; ends with a barrier.
-// Every wave derives the same per-slot decisions from the same LDS contents, so the branch
-// around the barriers is uniform.
+// Whether the staged loop (which contains barriers) runs is decided by a block-wide vote that is itself
+// a barrier (__syncthreads_or): all four waves take the same branch by construction, whatever each of
+// them read, and nothing below writes a point before every wave has taken its decisions.
 __device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact) {
     const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
     CoopSlot c{&m, s, (s + boff) & 63u, b_self ? kCoopA : kCoopB};
@@ -435,8 +436,7 @@ __device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, ui
     const bool ida = act && coop_is_identity(m, kCoopA, s);
     const bool idb = !act || coop_is_identity(m, c.bbase, c.sb);
     const bool live = act && !ida && !idb;
-    __syncthreads();  // every wave has taken its decisions before anything below writes a point
-    if (__any(live)) {
+    if (__syncthreads_or(live ? 1 : 0)) {
 #pragma unroll 1
         for (int stage = 0; stage < kCoopAddStages; stage++) {
             if (live) coop_add_stage(c, stage, (int)w);
@@ -460,7 +460,7 @@ __device__ __noinline__ void coop_dbl(CoopMem &m, bool want) {
     const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
     CoopSlot c{&m, s, s, kCoopA};
     const bool live = want && !coop_is_identity(m, kCoopA, s);
-    if (__any(live)) {
+    if (__syncthreads_or(live ? 1 : 0)) {
 #pragma unroll 1
         for (int stage = 0; stage < kCoopDblStages; stage++) {
             if (live) coop_dbl_stage(c, stage, (int)w);

@@ -129,6 +129,37 @@ def test_commit_skewed_buckets_known_answer(backend, log_n):
         assert same_point(backend.kzg_commit(sc), c.g1_mul(g, c.fr_eval(sc, tau))), name
 
 
+@pytest.mark.parametrize("window_bits", [4, 9, 13, 16])
+def test_cooperative_sums_meet_identity_equal_and_opposite_operands(backend, window_bits):
+    """The tail sums of small bucket arrays run on four cooperating waves whose barrier loops depend on every
+    wave taking the same per-slot decisions.  With every SRS point equal to G (tau = 1) and hand-picked
+    scalars the bucket sums that those waves add are equal (doubling path), opposite (sum is the identity),
+    or the identity itself, at window widths from a handful of buckets to 2^15 of them (with 16-bit windows
+    and 3 or 12 points: the shape of test_verification_key_commitments[16])."""
+    g = c.g1_generator()
+    backend.set_window_bits(window_bits)
+    try:
+        for n in (3, 12, 64):
+            backend.kzg_setup(c.fr_to_mont([1])[0], n - 1, want_points=False)
+            cases = {
+                "equal_buckets": [1 + (i & 1) for i in range(n)],            # B_0 = B_1 when n is even
+                "opposite": [1 if i & 1 else o.R - 1 for i in range(n)],     # +G and -G meet in bucket 0
+                "identity_heavy": [0] * (n - 1) + [5],
+                "mixed": [(1, o.R - 1, 2, o.R - 2, 3, 3)[i % 6] for i in range(n)],
+                "all_equal": [7] * n,
+                "zeros": [0] * n,
+            }
+            for name, vals in cases.items():
+                want = c.g1_mul(g, c.fr_to_mont([sum(vals) % o.R])[0])
+                got = backend.kzg_commit(c.fr_to_mont(vals))
+                assert same_point(got, want), (name, n, window_bits)
+                # the same twice in one batch: the deferred tails run side by side
+                both = backend.kzg_commit_batch([c.fr_to_mont(vals), c.fr_to_mont(vals[::-1])])
+                assert same_point(both[0], want) and same_point(both[1], want), (name, n, window_bits)
+    finally:
+        backend.set_window_bits(0)
+
+
 def test_commit_when_every_srs_point_is_the_generator(backend):
     # tau = 1: all points equal, so additions inside a bucket keep meeting equal operands (the
     # doubling path of the accumulation and of the tree sums); commit(f) == [sum f_i] G
