@@ -140,8 +140,10 @@ int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out);
 
 // sort.hip
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
-int sort_pairs(plonk_hip_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
-               uint32_t *vals_out, size_t n, int end_bit, void *temp, size_t temp_bytes);
+int sort_pairs_passes(int end_bit);
+// result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one
+int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
+               int end_bit, void *temp, size_t temp_bytes);
 
 // microbench.hip
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);

@@ -7,7 +7,7 @@
 //                                               of sign * table[w][i].
 // Pipeline (all on the context's stream, no host synchronisation):
 //   1. k_digits      scalars out of Montgomery form, nwin signed digits each -> (bucket, entry)
-//   2. sort_pairs    radix sort of the n*nwin pairs by bucket
+//   2. sort_pairs    radix sort of the n*nwin pairs by bucket (sort.hip)
 //   3. k_bounds      first sorted position of every bucket
 //   4. k_accumulate  one lane per fixed-length SEGMENT of the sorted list: gathers the affine
 //                    table points (one 128-byte line each) and adds them into an XYZZ
@@ -864,6 +864,10 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
                        pl.c, pl.nwin, nb, keys_a, vals_a);
     record(ctx, PH_SORT);
     PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
+    if ((sort_pairs_passes(pl.c) & 1) == 0) {  // an even number of passes ends in the first pair of buffers
+        keys_b = keys_a;
+        vals_b = vals_a;
+    }
     record(ctx, PH_BOUNDS);
     hipLaunchKernelGGL(k_bounds, dim3(cdiv(total, 256)), dim3(256), 0, st, keys_b, total, nb, start);
     // Fix-up shape: a typical bucket is cut into about per_bucket / seg_len + 1 partials; a group
