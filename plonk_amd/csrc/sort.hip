@@ -18,7 +18,10 @@
 
 namespace plonk {
 
-static constexpr int kSortThreads = 256, kSortItems = 32, kTile = kSortThreads * kSortItems;
+#ifndef PLONK_SORT_ITEMS
+#define PLONK_SORT_ITEMS 32
+#endif
+static constexpr int kSortThreads = 256, kSortItems = PLONK_SORT_ITEMS, kTile = kSortThreads * kSortItems;
 static constexpr int kSortWaves = kSortThreads / 64, kWaveSpan = 64 * kSortItems;
 static constexpr int kMaxBins = 256, kChunkTiles = 128;
 
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(kMaxBins) void k_radix_scan_chunks(uint32_t *__rest
     __shared__ uint32_t bin_total[kMaxBins];
     const uint32_t b = threadIdx.x;
     uint32_t run = 0;
+#pragma unroll 8
     for (uint32_t c = 0; c < nchunks; c++) {
         uint32_t *p = chunk_total + (size_t)c * kMaxBins + b;
         const uint32_t v = *p;
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(kMaxBins) void k_radix_scan_chunks(uint32_t *__rest
         __syncthreads();
     }
     const uint32_t base = bin_total[b] - run;  // inclusive - own = exclusive
+#pragma unroll 8
     for (uint32_t c = 0; c < nchunks; c++) chunk_total[(size_t)c * kMaxBins + b] += base;
 }
 
