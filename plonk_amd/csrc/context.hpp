@@ -95,6 +95,7 @@ struct plonk_hip_ctx {
     // this device's copy of the library's static scratch array (capi.hip), resolved at creation
     void *static_scratch = nullptr;
 
+    hipStream_t copy_stream = nullptr;  // host-to-device staging of large inputs beside the compute stream
     hipEvent_t timer_ev[2] = {};  // plonk_hip_timer_start / _stop
 
     bool profile = false;
@@ -128,8 +129,9 @@ MsmPlan msm_choose_plan(size_t srs_n, int override_bits);
 // d_scalars: n Montgomery scalars in device memory; d_out: one G1Jac in device memory.
 // overlap: defer the tail of this MSM (its result is written when msm_join runs the pending tails; the
 // caller calls msm_join before it reads d_out or returns).
+// first: scalar i multiplies SRS point first + i (a slice of a longer polynomial).
 int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out = nullptr,
-                bool overlap = false);
+                bool overlap = false, size_t first = 0);
 // runs the tails of all pending MSMs (one set of launches for all of them)
 int msm_join(plonk_hip_ctx *ctx);
 int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts, size_t first, size_t count,

@@ -55,9 +55,10 @@ __device__ __noinline__ G1Xyzz28 madd_slow_cold(const G1Xyzz28 *acc_lazy, const 
 // ------------------------------------------------------------------------------------------
 // 1. digits
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t srs_n, int c,
-                                               int nwin, uint32_t nbuckets, uint32_t *__restrict__ keys,
-                                               uint32_t *__restrict__ vals) {
+// scalar i multiplies SRS point first + i
+__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, uint32_t n, uint32_t srs_n,
+                                               uint32_t first, int c, int nwin, uint32_t nbuckets,
+                                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr k = fe_from_mont(scalars[i]);
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
         uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
         // digit 0 contributes nothing: key nbuckets sorts behind every real bucket
         uint32_t key = mag == 0 ? nbuckets : mag - 1;
-        uint32_t val = ((uint32_t)w * srs_n + i) | (d < 0 ? 0x80000000u : 0u);
+        uint32_t val = ((uint32_t)w * srs_n + first + i) | (d < 0 ? 0x80000000u : 0u);
         size_t at = (size_t)w * n + i;
         keys[at] = key;
         vals[at] = val;
@@ -809,10 +810,11 @@ int msm_reduce_slice_dev(plonk_hip_ctx *ctx, const void *d_parts, size_t nparts,
 
 // d_out: the MSM as a Jacobian point.  With d_buckets_out set (nbuckets x sizeof(G1Xyzz28) bytes of
 // device memory) the pipeline stops after the fix-up and leaves the bucket sums there instead.
-int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out, bool overlap) {
+int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out, void *d_buckets_out, bool overlap,
+                size_t first) {
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n == 0) return PLONK_HIP_ERR_EMPTY_POLY;
-    if (n > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    if (first > ctx->srs_n || n > ctx->srs_n - first) return PLONK_HIP_ERR_SRS_TOO_SHORT;
     const MsmPlan &pl = ctx->plan;
     const size_t total = n * (size_t)pl.nwin;
     if (total >= 0xfffffff0ull) return PLONK_HIP_ERR_INVALID_ARG;
@@ -861,7 +863,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
 
     record(ctx, PH_DIGITS);
     hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
-                       pl.c, pl.nwin, nb, keys_a, vals_a);
+                       (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
     record(ctx, PH_SORT);
     PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
     if ((sort_pairs_passes(pl.c) & 1) == 0) {  // an even number of passes ends in the first pair of buffers

@@ -344,3 +344,26 @@ def test_compiled_host_program_on_the_cpp_wrapper(backend):
     assert lines[4] == "roundtrip ok"
     assert lines[5].startswith("commit_error ") and "MISSING" not in lines[5]
     assert lines[6] == "panic ok"
+
+
+def test_large_host_commit_in_slices_equals_the_resident_commit(backend):
+    """Host coefficients of 2^23 and more go to the device in slices whose copies overlap the previous
+    slice's accumulation (each slice an MSM against its SRS range, tails side by side, partials added):
+    same commitment as the one-piece path on resident coefficients, and the known answer [f(tau)]G."""
+    n = (1 << 23) + 12345  # two uneven slices
+    rng = np.random.default_rng(23)
+    tau = c.fr_to_mont([0xABCDEF + (1 << 190)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    sc = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    got = backend.kzg_commit(sc)
+    d = backend.to_device(sc)
+    out = backend.malloc(144)
+    try:
+        backend.kzg_commit_dev(d, n, out)
+        backend.sync()
+        assert same_point(got, backend.from_device(out, (18,)))
+    finally:
+        backend.free(d)
+        backend.free(out)
+    assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
