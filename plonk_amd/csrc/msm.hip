@@ -79,16 +79,20 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
 // 3. bucket bounds: start[b] = first sorted position with key >= b, b = 0..nbuckets;
 //    start[nbuckets] = number of non-zero digits, start[nbuckets + 1] = total.
 // ------------------------------------------------------------------------------------------
+// One lane per bucket, a binary search each: the cost does not depend on how the keys are spread (a lane
+// per sorted position that fills in the buckets between its key and its neighbour's would loop over all
+// buckets when a short input meets a wide window plan).
 __global__ __launch_bounds__(256) void k_bounds(const uint32_t *__restrict__ keys, size_t total, uint32_t nbuckets,
                                                uint32_t *__restrict__ start) {
-    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    uint32_t k = keys[p];
-    uint32_t first = p == 0 ? 0u : keys[p - 1] + 1u;
-    for (uint32_t b = first; b <= k; b++) start[b] = (uint32_t)p;
-    if (p == total - 1) {
-        for (uint32_t b = k + 1; b <= nbuckets + 1; b++) start[b] = (uint32_t)total;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbuckets + 1) return;
+    uint32_t lo = 0, hi = (uint32_t)total;  // first position with key >= b lies in [lo, hi]
+    if (b > nbuckets) lo = hi;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < b) lo = mid + 1; else hi = mid;
     }
+    start[b] = lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -871,7 +875,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
         vals_b = vals_a;
     }
     record(ctx, PH_BOUNDS);
-    hipLaunchKernelGGL(k_bounds, dim3(cdiv(total, 256)), dim3(256), 0, st, keys_b, total, nb, start);
+    hipLaunchKernelGGL(k_bounds, dim3(cdiv((size_t)nb + 2, 256)), dim3(256), 0, st, keys_b, total, nb, start);
     // Fix-up shape: a typical bucket is cut into about per_bucket / seg_len + 1 partials; a group
     // of 2^g_log lanes takes up to per_lane partials per lane, anything longer (skewed digit
     // distributions: the narrow top window, repeated scalars) goes to the block path.
