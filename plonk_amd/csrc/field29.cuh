@@ -81,9 +81,36 @@ PLONK_HD Fr fr29_unpack(const Fr29 &a) {
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT29_ASM)
+// The product below as one hand-scheduled instruction sequence (mont29_asm.inc, written and checked by
+// scripts/gen_mont29_asm.py): 189 instructions against about 260 from the compiler, which splits the column
+// sums into independent chains and joins them with 64-bit additions.  The digits m_k are subtracted
+// (signed multiply-adds with -r_j), so that m_k is just the low 29 bits of the running column and no
+// product with r_0 = 1 is formed; the last digit is taken 2^29 lower, which adds r: the value is exactly
+// the one the portable form returns whenever that form's digits are not all zero.
+// Needs a's limbs below 2^30 (signed column sums), b's below 2^29.  Accumulator: v[2:3].
+__device__ __forceinline__ Fr29 fr29_mul_asm(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+    asm(
+#include "mont29_asm.inc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]),
+          "=&v"(r.l[7]), "=&v"(r.l[8])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+          "v"(a.l[8]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]),
+          "v"(b.l[7]), "v"(b.l[8]), "s"(0u - R29::mod(1)), "s"(0u - R29::mod(2)), "s"(0u - R29::mod(3)),
+          "s"(0u - R29::mod(4)), "s"(0u - R29::mod(5)), "s"(0u - R29::mod(6)), "s"(0u - R29::mod(7)),
+          "s"(0u - R29::mod(8)), "s"(R29::MASK), "s"(~R29::MASK)
+        : "vcc", "v2", "v3");
+    return r;
+}
+#endif
+
 // Montgomery product a*b/2^261 mod r, no final subtraction:
 // a < A * 2^255, b < r  =>  result < r * (1 + A / 64) ... precisely a*b/2^261 + r.
 PLONK_HD Fr29 fr29_mul_lazy(const Fr29 &a, const Fr29 &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT29_ASM)
+    return fr29_mul_asm(a, b);
+#else
     constexpr int N = R29::N;
     uint64_t acc = 0;
     uint32_t m[N];
@@ -109,6 +136,7 @@ PLONK_HD Fr29 fr29_mul_lazy(const Fr29 &a, const Fr29 &b) {
         acc >>= R29::BITS;
     }
     return r;
+#endif
 }
 
 // a + b, carries propagated, no reduction.

@@ -27,6 +27,7 @@
 // table of per-element factors applied at the first load or the last store: no separate pass.
 // All tables hold w * 2^261 in 29-bit limbs and are cached in the context per size and direction.
 #include "context.hpp"
+#define PLONK_MONT29_ASM 1  // the transforms' products as one hand-scheduled sequence
 #include "field29.cuh"
 #include "poly.hpp"
 
@@ -475,15 +476,34 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
         return ((T >> s0) << s1) | ((size_t)jr << s0) | (T & s0_mask);
     };
     const bool tile_fastest_in = s0 != 0 || in_map == 2, tile_fastest_out = s0 != 0 || out_map == 2;
-    for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) {
+    // element q of the block in load order: its place in memory, and its way into the LDS image with the
+    // factors that ride on a load
+    auto take = [&](const Fr &raw, uint32_t q) {
         const uint32_t tb = tile_fastest_in ? q & ((1u << tpb_log) - 1) : q >> k;
         const uint32_t j = tile_fastest_in ? q >> tpb_log : q & (tile_n - 1);
         const size_t T = first_tile + tb;
-        const size_t idx = address(in_map, T, j);
-        Fr29 v = fr29_pack(vec_in[idx]);
-        if (pre) v = fr29_mul_lazy(v, pre[idx].v);
+        Fr29 v = fr29_pack(raw);
+        if (pre) v = fr29_mul_lazy(v, pre[address(in_map, T, j)].v);
         if (!DIF && corr) v = fr29_mul_lazy(v, corr[((size_t)j << s0) | (T & s0_mask)].v);
         lds_put(lds + tb * tile_words, j, v);
+    };
+    auto where = [&](uint32_t q) -> size_t {
+        const uint32_t tb = tile_fastest_in ? q & ((1u << tpb_log) - 1) : q >> k;
+        const uint32_t j = tile_fastest_in ? q >> tpb_log : q & (tile_n - 1);
+        return address(in_map, first_tile + tb, j);
+    };
+    if (block_elems == 8 * blockDim.x) {
+        // all eight loads of a thread in flight together: one memory latency per block instead of eight
+        Fr raw[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) raw[e] = vec_in[where(threadIdx.x + e * blockDim.x)];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            take(raw[e], threadIdx.x + e * blockDim.x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) take(vec_in[where(q)], q);
     }
     __syncthreads();
 
