@@ -208,9 +208,64 @@ PLONK_HD constexpr uint32_t q28_kq(int i) {
     return out;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT28_ASM)
+// The lazy products below as hand-scheduled instruction sequences (mont28_*_asm.inc, written and checked by
+// scripts/gen_mont_asm.py): one dependent chain per product, the digits m_k subtracted with signed
+// multiply-adds (m_k = low limb of the running column times q^-1), the last digit taken 2^28 lower so that
+// the result comes out as a*b/2^392 + q at most, like the portable forms'.  The compiler's code for the
+// portable forms splits the column sums into independent chains and joins them with 64-bit additions.
+// Needs normalised limbs (below 2^28; the doubled operand of the squaring below 2^29).  Accumulator: v[2:3].
+#define PLONK_I14(x)                                                                                                  \
+    "v"(x.l[0]), "v"(x.l[1]), "v"(x.l[2]), "v"(x.l[3]), "v"(x.l[4]), "v"(x.l[5]), "v"(x.l[6]), "v"(x.l[7]), "v"(x.l[8]), \
+        "v"(x.l[9]), "v"(x.l[10]), "v"(x.l[11]), "v"(x.l[12]), "v"(x.l[13])
+#define PLONK_O14(x)                                                                                                  \
+    "=&v"(x.l[0]), "=&v"(x.l[1]), "=&v"(x.l[2]), "=&v"(x.l[3]), "=&v"(x.l[4]), "=&v"(x.l[5]), "=&v"(x.l[6]),            \
+        "=&v"(x.l[7]), "=&v"(x.l[8]), "=&v"(x.l[9]), "=&v"(x.l[10]), "=&v"(x.l[11]), "=&v"(x.l[12]), "=&v"(x.l[13])
+#define PLONK_Q14_CONSTANTS                                                                                            \
+    "s"(0u - Q28::mod(0)), "s"(0u - Q28::mod(1)), "s"(0u - Q28::mod(2)), "s"(0u - Q28::mod(3)), "s"(0u - Q28::mod(4)),   \
+        "s"(0u - Q28::mod(5)), "s"(0u - Q28::mod(6)), "s"(0u - Q28::mod(7)), "s"(0u - Q28::mod(8)),                      \
+        "s"(0u - Q28::mod(9)), "s"(0u - Q28::mod(10)), "s"(0u - Q28::mod(11)), "s"(0u - Q28::mod(12)),                   \
+        "s"(0u - Q28::mod(13)), "s"(Q28::MASK), "s"(~Q28::MASK), "s"((0u - Q28::INV) & Q28::MASK)
+__device__ __forceinline__ Fq28 q28_mul_asm(const Fq28 &a, const Fq28 &b) {
+    Fq28 r;
+    asm(
+#include "mont28_mul_asm.inc"
+        : PLONK_O14(r)
+        : PLONK_I14(a), PLONK_I14(b), PLONK_Q14_CONSTANTS
+        : "vcc", "v2", "v3");
+    return r;
+}
+__device__ __forceinline__ Fq28 q28_sqr_asm(const Fq28 &a) {
+    Fq28 a2, r;
+#pragma unroll
+    for (int i = 0; i < Q28::N; i++) a2.l[i] = a.l[i] << 1;
+    asm(
+#include "mont28_sqr_asm.inc"
+        : PLONK_O14(r)
+        : PLONK_I14(a), PLONK_I14(a2), PLONK_Q14_CONSTANTS
+        : "vcc", "v2", "v3");
+    return r;
+}
+__device__ __forceinline__ Fq28 q28_mul2_asm(const Fq28 &a, const Fq28 &b, const Fq28 &c, const Fq28 &d) {
+    Fq28 r;
+    asm(
+#include "mont28_mul2_asm.inc"
+        : PLONK_O14(r)
+        : PLONK_I14(a), PLONK_I14(b), PLONK_I14(c), PLONK_I14(d), PLONK_Q14_CONSTANTS
+        : "vcc", "v2", "v3");
+    return r;
+}
+#undef PLONK_I14
+#undef PLONK_O14
+#undef PLONK_Q14_CONSTANTS
+#endif
+
 // Montgomery product without the final conditional subtraction:
 // a < A*q, b < B*q  =>  result < (1 + A*B/2500) * q   (q / 2^392 < 1/2500).
 PLONK_HD Fq28 q28_mul_lazy(const Fq28 &a, const Fq28 &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT28_ASM)
+    return q28_mul_asm(a, b);
+#else
     constexpr int N = Q28::N;
     uint64_t acc = 0;
     uint32_t m[N];
@@ -236,12 +291,25 @@ PLONK_HD Fq28 q28_mul_lazy(const Fq28 &a, const Fq28 &b) {
         acc >>= Q28::BITS;
     }
     return r;
+#endif
+}
+
+// a * a / 2^392 mod q, lazy like q28_mul_lazy.
+PLONK_HD Fq28 q28_sqr_lazy(const Fq28 &a) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT28_ASM)
+    return q28_sqr_asm(a);
+#else
+    return q28_mul_lazy(a, a);  // (the compiler takes the off-diagonal products once)
+#endif
 }
 
 // (a*b + c*d) / 2^392 mod q with one reduction for both products:
 // a < A*q, b < B*q, c < C*q, d < D*q  =>  result < (1 + (A*B + C*D)/2500) * q.
 // A column holds at most 28 products and 14 reduction terms, each below 2^56: under 2^62.
 PLONK_HD Fq28 q28_mul2_lazy(const Fq28 &a, const Fq28 &b, const Fq28 &c, const Fq28 &d) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT28_ASM)
+    return q28_mul2_asm(a, b, c, d);
+#else
     constexpr int N = Q28::N;
     uint64_t acc = 0;
     uint32_t m[N];
@@ -271,6 +339,7 @@ PLONK_HD Fq28 q28_mul2_lazy(const Fq28 &a, const Fq28 &b, const Fq28 &c, const F
         acc >>= Q28::BITS;
     }
     return r;
+#endif
 }
 
 // (sign ? -a : a) - b + K*q in one carry pass.  Needs K*q >= b (+ a when sign is set).

@@ -83,7 +83,7 @@ PLONK_HD Fr fr29_unpack(const Fr29 &a) {
 
 #if defined(__HIP_DEVICE_COMPILE__) && defined(PLONK_MONT29_ASM)
 // The product below as one hand-scheduled instruction sequence (mont29_asm.inc, written and checked by
-// scripts/gen_mont29_asm.py): 189 instructions against about 260 from the compiler, which splits the column
+// scripts/gen_mont_asm.py): 189 instructions against about 230 from the compiler, which splits the column
 // sums into independent chains and joins them with 64-bit additions.  The digits m_k are subtracted
 // (signed multiply-adds with -r_j), so that m_k is just the low 29 bits of the running column and no
 // product with r_0 = 1 is formed; the last digit is taken 2^29 lower, which adds r: the value is exactly

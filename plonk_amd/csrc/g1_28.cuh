@@ -155,7 +155,7 @@ PLONK_HD bool xyzz28_madd_lazy(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2, bo
     PLONK_STEP();
     Fq28 R = q28_sub_lazy<5>(q28_mul_lazy(y2, acc.zzz), acc.y, negate);   // +-S2 - Y1    < 6.1 q
     PLONK_STEP();
-    Fq28 PP = q28_mul_lazy(P, P);                                         //              < 1.03 q
+    Fq28 PP = q28_sqr_lazy(P);                                            //              < 1.03 q
     if (q28_is_zero_mod_q(PP)) return false;
     PLONK_STEP();
     acc.zz = q28_mul_lazy(acc.zz, PP);
@@ -166,7 +166,7 @@ PLONK_HD bool xyzz28_madd_lazy(G1Xyzz28 &acc, const Fq28 &x2, const Fq28 &y2, bo
     PLONK_STEP();
     Fq28 Q = q28_mul_lazy(acc.x, PP);
     PLONK_STEP();
-    acc.x = q28_sub2_lazy<4>(q28_mul_lazy(R, R), PPP, Q);                 // R^2 - PPP - 2Q  < 5.1 q
+    acc.x = q28_sub2_lazy<4>(q28_sqr_lazy(R), PPP, Q);                 // R^2 - PPP - 2Q  < 5.1 q
     PLONK_STEP();
     // Y3 = R (Q - X3) - Y1 PPP as one double-width sum with a single reduction
     Fq28 negY = q28_sub_lazy<4>(q28_zero(), acc.y);                       // 4q - Y1      <= 4 q
@@ -184,12 +184,12 @@ PLONK_HD bool xyzz28_add_lazy(G1Xyzz28 &out, const G1Xyzz28 &a, const G1Xyzz28 &
     Fq28 P = q28_sub_lazy<2>(q28_mul_lazy(b.x, a.zz), U1);                // U2 - U1     < 3.1 q
     Fq28 S1 = q28_mul_lazy(a.y, b.zzz);
     Fq28 R = q28_sub_lazy<2>(q28_mul_lazy(b.y, a.zzz), S1);               // S2 - S1     < 3.1 q
-    Fq28 PP = q28_mul_lazy(P, P);                                         //             < 1.01 q
+    Fq28 PP = q28_sqr_lazy(P);                                            //             < 1.01 q
     if (q28_is_zero_mod_q(PP)) return false;
     Fq28 PPP = q28_mul_lazy(P, PP);
     Fq28 Q = q28_mul_lazy(U1, PP);
     G1Xyzz28 r;
-    r.x = q28_sub2_lazy<4>(q28_mul_lazy(R, R), PPP, Q);                   // R^2 - PPP - 2Q  < 5.1 q
+    r.x = q28_sub2_lazy<4>(q28_sqr_lazy(R), PPP, Q);                   // R^2 - PPP - 2Q  < 5.1 q
     Fq28 negS1 = q28_sub_lazy<2>(q28_zero(), S1);                         // 2q - S1     <= 2 q
     r.y = q28_mul2_lazy(R, q28_sub_lazy<6>(Q, r.x), negS1, PPP);          // R (Q - X3) - S1 PPP  < 1.1 q
     r.zz = q28_mul_lazy(q28_mul_lazy(a.zz, b.zz), PP);

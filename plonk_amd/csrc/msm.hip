@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "context.hpp"
+#define PLONK_MONT28_ASM 1  // the lazy Fq products as hand-scheduled sequences
 #include "coop28.cuh"
 #include "g1_28.cuh"
 #include "msm_core.cuh"
