@@ -67,9 +67,20 @@ static int bind(plonk_hip_ctx *ctx) {
 
 // Every entry point that touches the GPU holds the context's lock for its whole duration and
 // makes the context's device current on the calling thread.
+// Leaving the outermost entry point drops whatever deferred MSM tails are still pending: on the normal paths
+// msm_join has run them by then; after an error in the middle of a batch they must not run later, when
+// the output addresses they hold may no longer be valid.
+struct EntryScope {
+    plonk_hip_ctx *ctx;
+    explicit EntryScope(plonk_hip_ctx *c) : ctx(c) { ctx->entry_depth++; }
+    ~EntryScope() {
+        if (--ctx->entry_depth == 0) ctx->npending = 0;
+    }
+};
 #define PLONK_ENTER(ctx)                                        \
     if (!(ctx)) return PLONK_HIP_ERR_INVALID_ARG;               \
     std::lock_guard<std::recursive_mutex> _plonk_guard((ctx)->mu); \
+    EntryScope _plonk_scope(ctx);                               \
     PLONK_TRY(bind(ctx))
 
 static Fr load_fr(const uint64_t v[4]) {

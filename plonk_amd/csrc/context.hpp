@@ -73,6 +73,7 @@ struct plonk_hip_ctx {
     plonk::TailSlotBufs tail_bufs[plonk::kMaxTailSlots - 1];
     plonk::TailDesc pending[plonk::kMaxTailSlots];
     int npending = 0;
+    int entry_depth = 0;  // nesting of C entry points on this context (under `mu`)
     plonk::DevBuf scalars_stage, out_stage, stage_c;
     // generic scratch for SRS building and polynomial routines
     plonk::DevBuf scratch_a, scratch_b, scratch_c;
