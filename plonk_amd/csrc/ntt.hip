@@ -492,19 +492,9 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
         const uint32_t j = tile_fastest_in ? q >> tpb_log : q & (tile_n - 1);
         return address(in_map, first_tile + tb, j);
     };
-    if (block_elems == 8 * blockDim.x) {
-        // all eight loads of a thread in flight together: one memory latency per block instead of eight
-        Fr raw[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) raw[e] = vec_in[where(threadIdx.x + e * blockDim.x)];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            take(raw[e], threadIdx.x + e * blockDim.x);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) take(vec_in[where(q)], q);
-    }
+    // (One load in flight per thread: with all eight of a thread issued together, blocks that share 128-byte
+    // lines ask for them at the same moment and both fetch them -- a quarter more read traffic for 2 % of time.)
+    for (uint32_t q = threadIdx.x; q < block_elems; q += blockDim.x) take(vec_in[where(q)], q);
     __syncthreads();
 
     // a work item is 2^GMAX elements: GMAX = 3 keeps more stages in registers per LDS round trip,
