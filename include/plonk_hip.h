@@ -107,7 +107,7 @@ int plonk_hip_g1_compress(plonk_hip_ctx *ctx, const uint64_t *pts /* n x 18 */, 
 /* `kzg_setup(degree)` (kzg.rs:24-45) with tau supplied by the caller: computes [tau^i]G for
  * i = 0..degree on the GPU, installs the result as the context's SRS and, if out_pts is not
  * NULL, returns it ((degree+1) x 18).  The reference's own tau is `Fr::rand(test_rng())`;
- * drawing it stays on the caller's side.  tau_g2 (kzg.rs:39) is not produced here. */
+ * drawing it stays on the caller's side.  tau_g2 (kzg.rs:39): plonk_hip_kzg_setup_tau_g2 below. */
 int plonk_hip_kzg_setup(plonk_hip_ctx *ctx, const uint64_t tau[4], size_t degree, uint64_t *out_pts);
 /* The slice [tau^first .. tau^(first+count-1)]G of the same sequence: the SRS range one GPU
  * holds when a large commitment is sharded by point range (one context per GPU). */
@@ -159,6 +159,29 @@ int plonk_hip_kzg_open(plonk_hip_ctx *ctx, const uint64_t *coeffs /* n x 4 */, s
  * T at r, w*r, w^2*r).  us = m x 4, vs = m x 4, proofs = m x 18. */
 int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
                             uint64_t *vs, uint64_t *proofs);
+
+/* The G2 half of `kzg_setup` (kzg.rs:38-39): out = gp.tau_g2 = G2::generator() * tau in the 96-byte compressed
+ * form of plonk/data/srs.json.  Host code (no context, no GPU). */
+int plonk_hip_kzg_setup_tau_g2(const uint64_t tau[4], uint8_t out[96]);
+
+/* `kzg_verify(gp, com_f, u, v, proof)` (kzg.rs:91-98): *ok = [ e(com_f - v G, H) == e(proof, tau H - u H) ].
+ * Host code (no context, no GPU): the check is taken as e(com_f - v G + u proof, H) * e(-proof, tau H) == 1, so
+ * only G1 arithmetic depends on the arguments; the Miller-loop lines of H and tau H are computed once per
+ * tau_g2 and kept.  tau_g2 = gp.tau_g2 (kzg.rs:20) in the 96-byte compressed form of plonk/data/srs.json; it is
+ * validated (encoding, curve, subgroup) when first seen: PLONK_HIP_ERR_INVALID_POINT otherwise.  com and proof
+ * are Jacobian points as everywhere in this interface and are taken as valid group elements (the reference's
+ * types guarantee it); u, v Montgomery limbs. */
+int plonk_hip_kzg_verify(const uint8_t tau_g2[96], const uint64_t com[18], const uint64_t u[4], const uint64_t v[4],
+                         const uint64_t proof[18], int *ok);
+/* The n kzg_verify calls of one proof (15 in the reference's verifier: protocols.rs:229-231, 706-718, 804-808,
+ * verifier/part4.rs:20-29) as ONE pairing-product check: with weights rho_i,
+ *   L = sum rho_i (com_i - v_i G + u_i proof_i),  R = sum rho_i proof_i,  *ok = [ e(L, H) == e(R, tau H) ]:
+ * two Miller loops and one final exponentiation instead of 2 n pairings.  rho = n x 2 words, the weights as
+ * 128-bit integers (little-endian words); they must be drawn after the proofs are fixed and be unpredictable
+ * to their author (rho_0 = 1 is fine): then *ok == 1 means every single check holds, except with probability
+ * about n / 2^128.  coms, proofs = n x 18; us, vs = n x 4.  n == 0: *ok = 1. */
+int plonk_hip_kzg_verify_batch(const uint8_t tau_g2[96], size_t n, const uint64_t *coms, const uint64_t *us,
+                               const uint64_t *vs, const uint64_t *proofs, const uint64_t *rho, int *ok);
 
 /* GPU time of whatever is enqueued on the context's stream between the two calls (HIP events on that stream;
  * _stop waits for the work to finish).  For measurement harnesses: a framework's own events only see the

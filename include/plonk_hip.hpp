@@ -108,6 +108,35 @@ inline std::pair<Fr, G1> kzg_evaluate(const GlobalParameters &gp, const DensePol
     return {v, proof};
 }
 
+// gp.tau_g2 (kzg.rs:20, 38-39) in its 96-byte compressed form, and kzg_verify (kzg.rs:91-98) on it
+using G2Compressed = std::array<uint8_t, 96>;
+inline G2Compressed kzg_setup_tau_g2(const Fr &tau) {
+    G2Compressed out;
+    if (int rc = plonk_hip_kzg_setup_tau_g2(tau.data(), out.data())) throw Error(rc, plonk_hip_strerror(rc));
+    return out;
+}
+inline bool kzg_verify(const G2Compressed &tau_g2, const G1 &com_f, const Fr &u, const Fr &v, const G1 &proof) {
+    int ok = 0;
+    if (int rc = plonk_hip_kzg_verify(tau_g2.data(), com_f.data(), u.data(), v.data(), proof.data(), &ok))
+        throw Error(rc, plonk_hip_strerror(rc));
+    return ok != 0;
+}
+// every (com_f, u, v, proof) at once; rho: one 128-bit weight per check (two words each), drawn by the caller
+// after the proofs are fixed
+inline bool kzg_verify_batch(const G2Compressed &tau_g2, const std::vector<G1> &coms, const std::vector<Fr> &us,
+                             const std::vector<Fr> &vs, const std::vector<G1> &proofs,
+                             const std::vector<std::array<uint64_t, 2>> &rho) {
+    const size_t n = coms.size();
+    if (us.size() != n || vs.size() != n || proofs.size() != n || rho.size() < n)
+        throw Error(PLONK_HIP_ERR_INVALID_ARG, plonk_hip_strerror(PLONK_HIP_ERR_INVALID_ARG));
+    int ok = 0;
+    if (int rc = plonk_hip_kzg_verify_batch(tau_g2.data(), n, n ? coms[0].data() : nullptr, n ? us[0].data() : nullptr,
+                                            n ? vs[0].data() : nullptr, n ? proofs[0].data() : nullptr,
+                                            n ? rho[0].data() : nullptr, &ok))
+        throw Error(rc, plonk_hip_strerror(rc));
+    return ok != 0;
+}
+
 // interpolate_polynomial(construct_Omega(n), ys) for n = 2^k or 3 * 2^k
 inline DensePolynomial interpolate_over_omega(const GlobalParameters &gp, std::vector<Fr> ys) {
     if (!ys.empty()) gp.check(plonk_hip_fr_ntt_mixed(gp.ctx(), ys[0].data(), ys.size(), 1, 1));

@@ -37,6 +37,48 @@ def _fr(a, cols=4):
     return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, cols)
 
 
+def _host_check(rc):
+    if rc != 0:
+        text = _l.load_library().plonk_hip_strerror(rc).decode()
+        raise (ReferencePanic if rc == ERR_INVALID_POINT else PlonkHipError)(rc, text)
+
+
+def kzg_setup_tau_g2(tau):
+    """gp.tau_g2 of `kzg_setup` (plonk/src/common/kzg.rs:38-39) for the trapdoor tau (4 Montgomery limbs): 96
+    bytes, compressed.  Host code."""
+    out = ctypes.create_string_buffer(96)
+    _host_check(_l.load_library().plonk_hip_kzg_setup_tau_g2(_u64(_fr(tau)), out))
+    return out.raw
+
+
+def kzg_verify(tau_g2, com, u, v, proof):
+    """`kzg_verify(gp, com_f, u, v, proof)` (plonk/src/common/kzg.rs:91-98).  tau_g2: the 96-byte compressed
+    gp.tau_g2; com, proof: 18 limbs; u, v: 4 limbs (Montgomery).  Host code: needs no context and no GPU."""
+    ok = ctypes.c_int(0)
+    _host_check(_l.load_library().plonk_hip_kzg_verify(bytes(tau_g2), _u64(_fr(com, 18)), _u64(_fr(u)), _u64(_fr(v)),
+                                                       _u64(_fr(proof, 18)), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+def kzg_verify_batch(tau_g2, coms, us, vs, proofs, rho=None):
+    """All of a proof's kzg_verify calls as one pairing-product check (two Miller loops, one final
+    exponentiation).  coms, proofs: (n, 18); us, vs: (n, 4); rho: (n, 2) 128-bit weights, drawn from the
+    operating system's generator when not given (the first one is 1)."""
+    coms, proofs, us, vs = _fr(coms, 18), _fr(proofs, 18), _fr(us), _fr(vs)
+    n = coms.shape[0]
+    assert proofs.shape[0] == n and us.shape[0] == n and vs.shape[0] == n
+    if rho is None:
+        import os
+        rho = np.frombuffer(os.urandom(16 * max(n, 1)), dtype=np.uint64).reshape(-1, 2).copy()
+        rho[0] = (1, 0)
+    rho = _fr(rho, 2)
+    assert rho.shape[0] >= n
+    ok = ctypes.c_int(0)
+    _host_check(_l.load_library().plonk_hip_kzg_verify_batch(bytes(tau_g2), n, _u64(coms), _u64(us), _u64(vs),
+                                                             _u64(proofs), _u64(rho), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
 class Backend:
     def __init__(self, device=0, window_bits=0):
         self._lib = _l.load_library()

@@ -44,6 +44,10 @@ SIGNATURES = {
     "plonk_hip_kzg_open": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, c_u64p, c_u64p]),
     "plonk_hip_kzg_open_many": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p, c_u64p]),
+    "plonk_hip_kzg_setup_tau_g2": (ctypes.c_int, [c_u64p, ctypes.c_char_p]),
+    "plonk_hip_kzg_verify": (ctypes.c_int, [ctypes.c_char_p, c_u64p, c_u64p, c_u64p, c_u64p, c_intp]),
+    "plonk_hip_kzg_verify_batch": (
+        ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, c_u64p, c_u64p, c_u64p, c_u64p, c_u64p, c_intp]),
     "plonk_hip_profile": (ctypes.c_int, [c_ctx, ctypes.c_int]),
     "plonk_hip_timer_start": (ctypes.c_int, [c_ctx]),
     "plonk_hip_timer_stop": (ctypes.c_int, [c_ctx, c_floatp]),

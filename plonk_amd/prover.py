@@ -242,6 +242,40 @@ class Prover:
                 raise AssertionError("commitment or opening proof does not match the trapdoor evaluation")
         return len(self.kzg_log)
 
+    def opening_checks(self, known=()):
+        """(coms, us, vs, proofs) of every logged opening, as `kzg_verify_batch` takes them.  The commitment of
+        an opened polynomial is the logged one when the prover committed to it, one of `known` =
+        [(coefficients, commitment), ...] when its coefficients equal those (S and W come with the keys), and
+        is computed otherwise."""
+        committed = {id(poly): point for poly, point, u, _ in self.kzg_log if u is None}
+        coms, us, vs, proofs = [], [], [], []
+        for poly, point, u, v in self.kzg_log:
+            if u is None:
+                continue
+            if id(poly) not in committed:
+                for coeffs, com in known:
+                    a, b = trim(np.asarray(poly)), trim(np.asarray(coeffs))
+                    if a.shape == b.shape and np.array_equal(a, b):
+                        committed[id(poly)] = np.array(com)
+                        break
+                else:
+                    committed[id(poly)] = np.array(self.be.kzg_commit(poly))
+            coms.append(committed[id(poly)])
+            us.append(u)
+            vs.append(v)
+            proofs.append(point)
+        if not coms:
+            return np.zeros((0, 18), np.uint64), np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64), \
+                np.zeros((0, 18), np.uint64)
+        return np.stack(coms), to_mont(us), to_mont(vs), np.stack(proofs)
+
+    def verify_openings(self, tau_g2, rho=None, known=()):
+        """Every logged opening checked as the reference's verifier does, by pairings (kzg_verify,
+        plonk/src/common/kzg.rs:91-98), all of them folded into one pairing-product check
+        (`kzg_verify_batch`).  tau_g2: gp.tau_g2, 96 bytes.  Needs the public parameters only, no trapdoor."""
+        from .backend import kzg_verify_batch
+        return kzg_verify_batch(tau_g2, *self.opening_checks(known), rho)
+
     def check_identities(self, circuit_shape, proof, keys):
         """The field equations of the verifier (verify_zero_on_roots_test protocols.rs:220-229,
         verify_T_S_zero_test :789-803, verify_prescribed_permutation_check :702-705) on the opened
@@ -578,7 +612,11 @@ class Prover:
                   "g_w_rp": val[15], "proof_g_w_rp": g1[15], "W_w_rp": val[16], "proof_W_w_rp": g1[16]}
             out_proof = g1[17]
             if self.kzg_log is not None:  # the audit reads the polynomials after the buffers are gone
-                self.kzg_log = [(be.from_device(buf[0], (buf[1], 4)), g, u, v) for buf, g, u, v in self.kzg_log]
+                host = {}  # one host array per device buffer: entries of one polynomial share it
+                for buf, _, _, _ in self.kzg_log:
+                    if (buf[0], buf[1]) not in host:
+                        host[(buf[0], buf[1])] = be.from_device(buf[0], (buf[1], 4))
+                self.kzg_log = [(host[(buf[0], buf[1])], g, u, v) for buf, g, u, v in self.kzg_log]
         finally:
             pool.release()
         return self._proof_json(circuit, com_T, p2, p3, p4, out_proof)

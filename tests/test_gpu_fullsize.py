@@ -97,6 +97,8 @@ def test_proof_of_a_circuit_of_2_to_20_gates():
         proof = p.prove_resident(circuit, keys)
         assert p.audit_with_tau(tau) >= 2  # every logged commitment / opening equals [f(tau)]G / [q(tau)]G
         assert p.check_identities((circuit.number_gates, circuit.pub_inputs), proof, keys)
+        # the openings by pairings, folded into one check (public parameters only)
+        assert p.verify_openings(plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau])[0]))
         p.kzg_log = None
         assert p.prove_resident(circuit, keys) == proof  # deterministic
     finally:

@@ -187,6 +187,11 @@ def test_limb_array_prover_matches_the_restatement(backend, log_gates):
     assert p.audit_with_tau(tau) == 6 + 14  # T is opened at w rp once for f and g
     shape = (circuit.number_gates, circuit.pub_inputs)
     assert p.check_identities(shape, proof, keys)
+    # ... and every opening as the reference's verifier checks it: by pairings, with the public tau_g2 only
+    import plonk_amd
+    tau_g2 = plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau])[0])
+    assert p.verify_openings(tau_g2)
+    assert not p.verify_openings(plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau + 1])[0]))
     forged = dict(proof)
     forged["proof_T_S_zero"] = list(proof["proof_T_S_zero"])
     forged["proof_T_S_zero"][1] = str((int(proof["proof_T_S_zero"][1]) + 1) % pv.R_MOD)
