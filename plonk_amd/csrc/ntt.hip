@@ -19,8 +19,8 @@
 // lowest in-tile bits use 1, omega_4, omega_8 and omega_8^3 from scalar registers, and the
 // multiplications by 1 are skipped: 7 of every 40 butterflies of a 10-stage pass).  What the true
 // twiddle omega_(2^s1)^((j_low << s0 | t_lo) << ...) has on top of that is collected into ONE factor
-// per element, omega_(2^s1)^(t_lo * rev(j)), applied when a strided pass stores (DIF) or loads
-// (DIT).  Those factors come from a table laid out like the data ((j << s0) | t_lo), so they are
+// per element, omega_(2^s1)^(t_lo * rev(j)), applied when a strided pass stores (DIF) or, for DIT, when the
+// pass before it stores.  Those factors come from a table laid out like the data ((j << s0) | t_lo), so they are
 // read in the same contiguous rows as the data, and a batch is dealt to the eight XCDs by tile
 // rather than by vector, so that one XCD's L2 serves a table row to all vectors of the batch.
 // A coset shift (f(gX) before a forward transform, g^-i / n after an inverse one) is one more
@@ -418,6 +418,9 @@ struct PassArgs {
     int do_scale, canonical_out, in_map, out_map, xcd_map;
     uint32_t xcd_group_log;  // with xcd_map: 2^xcd_group_log neighbouring tile blocks stay on one XCD
     Fr29 scale, scale_upper;
+    // DIT: the factors of the NEXT pass (stages [next_s0, next_s1), its load map next_map) ride on this pass's store
+    uint32_t next_s0, next_s1;
+    int next_map;
 };
 
 // One pass over the stages [s0, s1) (3 <= s1 - s0 <= 11).  A block owns `tiles_per_block`
@@ -425,8 +428,12 @@ struct PassArgs {
 // cross HBM as 8 x 32-bit limbs (values below 2^256; canonical when `canonical_out` is set, as
 // on the last pass).
 //   tw    powers of the primitive 2^(s1-s0)-th root (direction as the transform's)
-//   corr  strided passes: the per-element factors described at the top of the file, at (j << s0) | t_lo
-//         (DIF multiplies when it stores, DIT when it loads); null on the pass with s0 = 0
+//   corr  strided DIF passes: the per-element factors described at the top of the file, at (j << s0) | t_lo,
+//         multiplied in when the pass stores; null otherwise
+//   corr_next  DIT: the factors of the strided pass that comes NEXT, multiplied in when this pass stores (the
+//         product is below 2 r, so it fits the 256-bit format without the two reduction steps a plain store
+//         needs, and the next pass loads plain values); the element stored at address A is element
+//         j = row(A) (bit-reversed when the next pass loads through map 1) of its tile there; null on the last pass
 //   pre   a factor per input element, by address (coset shift of a forward transform), or null
 //   post  a factor per output element, by address (coset shift and 1/n of an inverse transform), or null
 // `scale` (w * 2^261 form) multiplies every output when do_scale is 1 and post is null; with do_scale 2
@@ -439,8 +446,9 @@ struct PassArgs {
 // line between them would each fetch all of it if they sat on XCDs with separate L2s).
 template <bool DIF, int GMAX>
 __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *src, Fr *dst, const Tw29 *__restrict__ tw,
-                                                  const Tw29 *__restrict__ corr, const Tw29 *__restrict__ pre,
-                                                  const Tw29 *__restrict__ post, PassArgs a) {
+                                                  const Tw29 *__restrict__ corr, const Tw29 *__restrict__ corr_next,
+                                                  const Tw29 *__restrict__ pre, const Tw29 *__restrict__ post,
+                                                  PassArgs a) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t log_n = a.log_n, s0 = a.s0, s1 = a.s1, tpb_log = a.tpb_log;
     const uint32_t k = s1 - s0;
@@ -484,7 +492,6 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
         const size_t T = first_tile + tb;
         Fr29 v = fr29_pack(raw);
         if (pre) v = fr29_mul_lazy(v, pre[address(in_map, T, j)].v);
-        if (!DIF && corr) v = fr29_mul_lazy(v, corr[((size_t)j << s0) | (T & s0_mask)].v);
         lds_put(lds + tb * tile_words, j, v);
     };
     auto where = [&](uint32_t q) -> size_t {
@@ -538,6 +545,15 @@ __global__ __launch_bounds__(256, GMAX == 2 ? 4 : 2) void k_ntt_pass(const Fr *s
         bool product = false;  // a product is below 2 r
         if (DIF && corr) {
             v = fr29_mul_lazy(v, corr[((size_t)j << s0) | (T & s0_mask)].v);
+            product = true;
+        }
+        if (!DIF && corr_next) {
+            const uint32_t kn = a.next_s1 - a.next_s0;
+            const uint32_t row = (uint32_t)(idx >> a.next_s0) & ((1u << kn) - 1);
+            const uint32_t jn = a.next_map ? (__brev(row) >> (32 - kn)) : row;
+            const size_t at = (((size_t)jn << a.next_s0) | (idx & (((size_t)1 << a.next_s0) - 1))) &
+                              (((size_t)1 << a.next_s1) - 1);
+            v = fr29_mul_lazy(v, corr_next[at].v);
             product = true;
         }
         if (post) {
@@ -776,7 +792,18 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         const bool rows = pl.s0[i] != 0 || a.in_map == 2 || a.out_map == 2;
         uint32_t group_log = 0;
         while (rows && (32u << (tpb_log + group_log)) < 128u) group_log++;
-        const bool tables = batch > 1 && (corrs[i] || pass_pre || pass_post);
+        // DIF multiplies its factors in when the strided pass stores; DIT hands the factors of pass q + 1 to
+        // the store of pass q
+        const Tw29 *corr_store = dif ? corrs[i] : nullptr, *corr_next = nullptr;
+        a.next_s0 = a.next_s1 = 0;
+        a.next_map = 0;
+        if (!dif && !last) {
+            corr_next = corrs[i + 1];
+            a.next_s0 = pl.s0[i + 1];
+            a.next_s1 = pl.s1[i + 1];
+            a.next_map = natural ? 1 : 0;
+        }
+        const bool tables = batch > 1 && (corr_store || corr_next || pass_pre || pass_post);
         if ((group_log || tables) && a.tile_blocks % (8u << group_log) == 0) {
             a.xcd_map = 1;
             a.xcd_group_log = group_log;
@@ -784,11 +811,11 @@ static int run_passes(plonk_hip_ctx *ctx, Fr *d, uint32_t log_n, size_t batch, b
         const dim3 grid(a.tile_blocks * (unsigned)batch);
         // (a two-stage variant, GMAX = 2, runs four waves per SIMD at the same speed)
         if (dif) {
-            hipLaunchKernelGGL((k_ntt_pass<true, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corrs[i],
-                               pass_pre, pass_post, a);
+            hipLaunchKernelGGL((k_ntt_pass<true, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corr_store,
+                               corr_next, pass_pre, pass_post, a);
         } else {
-            hipLaunchKernelGGL((k_ntt_pass<false, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corrs[i],
-                               pass_pre, pass_post, a);
+            hipLaunchKernelGGL((k_ntt_pass<false, 3>), grid, dim3(threads), lds, ctx->stream, src, dst, tws[i], corr_store,
+                               corr_next, pass_pre, pass_post, a);
         }
     }
     return PLONK_HIP_OK;
