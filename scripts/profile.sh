@@ -30,6 +30,9 @@ pass() {  # name, counters, command...
 # the whole default bench (extras included) as a kernel trace with per-kernel statistics
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -- \
     python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_${TAG}_stats.log 2>&1 || exit 1
+# the headline command alone (2^24 commitments only): its per-kernel averages are per 2^24 launch
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_msm -- \
+    python3 $MSM > $OUT/prof_${TAG}_stats_msm.log 2>&1 || exit 1
 pass msm_sq1 "$SQ1" $MSM
 pass msm_sq2 "$SQ2" $MSM
 pass msm_fetch FETCH_SIZE $MSM
