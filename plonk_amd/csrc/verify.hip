@@ -533,8 +533,9 @@ struct PreparedPair {
     Prepared h, tau_h;
     bool valid = false;
 };
-// The prepared (H, tau H) of the last tau_g2 seen; -1: not a valid G2 encoding / not in the subgroup.
-static int prepared_for(const uint8_t tau_g2[96], const PreparedPair **out) {
+// The prepared (H, tau H) of the last tau_g2 seen, copied out under the lock (callers on other threads may
+// replace the cached pair at any time); -1: not a valid G2 encoding / not in the subgroup.
+static int prepared_for(const uint8_t tau_g2[96], PreparedPair *out) {
     static PreparedPair cache;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
@@ -547,7 +548,7 @@ static int prepared_for(const uint8_t tau_g2[96], const PreparedPair **out) {
         memcpy(cache.tau_encoding, tau_g2, 96);
         cache.valid = true;
     }
-    *out = &cache;
+    *out = cache;
     return 0;
 }
 
@@ -641,8 +642,9 @@ static Fr fr_from_u128(const uint64_t w[2]) {
 
 static int verify_folded(const uint8_t tau_g2[96], size_t n, const uint64_t *coms, const uint64_t *us,
                          const uint64_t *vs, const uint64_t *proofs, const uint64_t *rho, int *ok) {
-    const PreparedPair *g2 = nullptr;
-    if (prepared_for(tau_g2, &g2) != 0) return PLONK_HIP_ERR_INVALID_POINT;
+    PreparedPair pair;
+    if (prepared_for(tau_g2, &pair) != 0) return PLONK_HIP_ERR_INVALID_POINT;
+    const PreparedPair *g2 = &pair;
     // L = sum rho_i com_i + sum (rho_i u_i) proof_i - (sum rho_i v_i) G,   R = sum rho_i proof_i
     std::vector<Term> left, right;
     left.reserve(2 * n + 1);
