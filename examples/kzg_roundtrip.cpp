@@ -1,4 +1,4 @@
-// A compiled host program on plonk_hip.hpp: the shape of plonk/tests/kzg_tests.rs (setup, commit, open,
+// A compiled host program on plonk_hip.hpp: the shape of plonk/tests/kzg_tests.rs (setup, commit, open, verify,
 // SRS too short) plus an interpolation round trip.  Input on the command line: the trapdoor and the point
 // as 4 limbs each (Montgomery form, hex), then the coefficients as raw limbs on stdin.  Prints the
 // compressed commitment, the opened value (limbs) and the compressed proof as hex lines; the test harness
@@ -41,12 +41,18 @@ int main(int argc, char **argv) {
         std::printf("%016llx %016llx %016llx %016llx\n", (unsigned long long)v[0], (unsigned long long)v[1],
                     (unsigned long long)v[2], (unsigned long long)v[3]);
         print_hex(enc[1].data(), 48);
+        // plonk/tests/kzg_tests.rs:148-197: the opening verifies by pairings against gp.tau_g2, a wrong value does not
+        const G2Compressed tau_g2 = kzg_setup_tau_g2(tau);
+        Fr wrong = v;
+        wrong[0] ^= 1;
+        const bool verified = kzg_verify(tau_g2, com, u, v, proof) && !kzg_verify(tau_g2, com, u, wrong, proof);
         // interpolation over Omega is the inverse of evaluation over Omega
         size_t n = 1;
         while (n < f.size()) n *= 2;
         DensePolynomial back = interpolate_over_omega(gp, evaluate_over_omega(gp, f, n));
         back.resize(f.size());
         std::printf("roundtrip %s\n", back == f ? "ok" : "MISMATCH");
+        std::printf("verify %s\n", verified ? "ok" : "FAILED");
         // plonk/tests/kzg_tests.rs:71-93: a polynomial longer than the SRS is a CommitError
         DensePolynomial too_long(degree + 2, Fr{1, 0, 0, 0});
         try {

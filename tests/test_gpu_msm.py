@@ -342,15 +342,17 @@ def test_compiled_host_program_on_the_cpp_wrapper(backend):
     want = c.g1_mul(c.g1_generator(), c.fr_to_mont([quotient_at_tau])[0])
     assert lines[3] == c.g1_compress(want.reshape(1, 18))[0].hex()
     assert lines[4] == "roundtrip ok"
-    assert lines[5].startswith("commit_error ") and "MISSING" not in lines[5]
-    assert lines[6] == "panic ok"
+    assert lines[5] == "verify ok"
+    assert lines[6].startswith("commit_error ") and "MISSING" not in lines[6]
+    assert lines[7] == "panic ok"
 
 
-def test_large_host_commit_in_slices_equals_the_resident_commit(backend):
+@pytest.mark.parametrize("n", [(1 << 23) + 12345, (1 << 24) + 777])
+def test_large_host_commit_in_slices_equals_the_resident_commit(backend, n):
     """Host coefficients of 2^23 and more go to the device in slices whose copies overlap the previous
     slice's accumulation (each slice an MSM against its SRS range, tails side by side, partials added):
-    same commitment as the one-piece path on resident coefficients, and the known answer [f(tau)]G."""
-    n = (1 << 23) + 12345  # two uneven slices
+    same commitment as the one-piece path on resident coefficients, and the known answer [f(tau)]G.
+    The two sizes: two equal slices; four slices of an eighth, an eighth, a quarter and the rest."""
     rng = np.random.default_rng(23)
     tau = c.fr_to_mont([0xABCDEF + (1 << 190)])[0]
     backend.kzg_setup(tau, n - 1, want_points=False)
@@ -367,3 +369,23 @@ def test_large_host_commit_in_slices_equals_the_resident_commit(backend):
         backend.free(d)
         backend.free(out)
     assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
+
+
+def test_full_kzg_protocol_like_the_reference_test(backend):
+    """plonk/tests/kzg_tests.rs:199-227: ten random degrees up to 100: setup, commit, evaluate at a random point,
+    verify by pairings -- every step through the library.  (A constant polynomial has an empty quotient: the
+    reference's kzg_evaluate panics on it, kzg.rs:85.)"""
+    rnd = random.Random(199)
+    for degree in [1, 2, 100] + [rnd.randrange(1, 101) for _ in range(7)]:
+        tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+        backend.kzg_setup(tau, degree, want_points=False)
+        f = c.fr_to_mont(rand_fr(rnd, degree + 1))
+        com_f = backend.kzg_commit(f)
+        u = c.fr_to_mont([rnd.randrange(o.R)])[0]
+        v, proof = backend.kzg_evaluate(f, u)
+        tau_g2 = plonk_amd.kzg_setup_tau_g2(tau)
+        assert plonk_amd.kzg_verify(tau_g2, com_f, u, v, proof), degree
+        assert not plonk_amd.kzg_verify(tau_g2, com_f, u, c.fr_to_mont([1])[0], proof), degree
+    backend.kzg_setup(c.fr_to_mont([5])[0], 0, want_points=False)
+    with pytest.raises(plonk_amd.ReferencePanic):
+        backend.kzg_evaluate(c.fr_to_mont([7]), c.fr_to_mont([3])[0])

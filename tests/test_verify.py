@@ -146,3 +146,21 @@ def test_openings_verify_under_a_fresh_srs():
     assert plonk_amd.kzg_verify(tau_g2, coms[0], us[0], vs[0], proofs[0])
     assert not plonk_amd.kzg_verify(plonk_amd.kzg_setup_tau_g2(oc.fr_to_mont([tau + 1])[0]), coms[0], us[0], vs[0],
                                     proofs[0])
+
+
+def test_kzg_verify_like_the_reference_test():
+    """plonk/tests/kzg_tests.rs:148-197: com_f = [f(tau)]G and proof = [q(tau)]G, q = (f - v) / (X - u), computed from
+    the trapdoor directly; kzg_verify must return true."""
+    import random
+    rnd = random.Random(148)
+    tau = rnd.randrange(1, o.R)
+    f = [rnd.randrange(o.R) for _ in range(11)]  # degree 10
+    u = rnd.randrange(o.R)
+    v = o.poly_eval(f, u)
+    q, rem = o.poly_divmod(o.poly_sub(f, [v]), [(-u) % o.R, 1])
+    assert o.poly_trim(rem) == []
+    com_f = o.g1_mul(o.G1_GENERATOR, o.poly_eval(f, tau))
+    proof = o.g1_mul(o.G1_GENERATOR, o.poly_eval(q, tau))
+    coms, us, vs, proofs = _arrays([(com_f, u, v, proof)])
+    tau_g2 = plonk_amd.kzg_setup_tau_g2(oc.fr_to_mont([tau])[0])
+    assert plonk_amd.kzg_verify(tau_g2, coms[0], us[0], vs[0], proofs[0])
