@@ -296,6 +296,7 @@ def time_small_msm(log_n, reps, mad_peak):
 
 
 VERIFY_FOLD_SECONDS = None
+VERIFY_RUN_SECONDS = None
 
 
 def time_prover(log_gates, device_index=0, ranks=None, barrier=None):
@@ -322,8 +323,17 @@ def time_prover(log_gates, device_index=0, ranks=None, barrier=None):
     ok = ok and plonk_amd.kzg_verify_batch(tau_g2, *checks)  # (the first call also prepares the G2 side)
     t0 = time.perf_counter()
     ok = ok and plonk_amd.kzg_verify_batch(tau_g2, *checks)
-    global VERIFY_FOLD_SECONDS
+    global VERIFY_FOLD_SECONDS, VERIFY_RUN_SECONDS
     VERIFY_FOLD_SECONDS = time.perf_counter() - t0
+    if ranks is None:
+        # the whole verifier on the serialised proof (verifier::run): decode, challenges, field equations, fold
+        from plonk_amd import verifier
+        vk = {"com_S": p.hex_of(keys["com_S"]), "com_W": p.hex_of(keys["com_W"])}
+        vf = verifier.Verifier(be, circuit.d, circuit.number_gates, len(circuit.pub_inputs), tau_g2)
+        ok = ok and vf.run(vk, proof)
+        t0 = time.perf_counter()
+        ok = ok and vf.run(vk, proof)
+        VERIFY_RUN_SECONDS = time.perf_counter() - t0
     p.kzg_log = None
     if barrier:
         barrier()
@@ -686,9 +696,13 @@ def main():
                         args.prover_log_gates, args.prover_log_gates, checked))
                 if VERIFY_FOLD_SECONDS is not None:
                     extras["verify_openings_folded_ms"] = round(VERIFY_FOLD_SECONDS * 1e3, 1)
+                    if VERIFY_RUN_SECONDS is not None:
+                        extras["verify_latency_ms"] = round(VERIFY_RUN_SECONDS * 1e3, 1)
                     extras["verify_openings_note"] = (
                         "the proof's openings checked by pairings as ONE pairing-product check (host code: two Miller "
-                        "loops, one final exponentiation, two small G1 multi-scalar sums), commitments already at hand")
+                        "loops, one final exponentiation, two small G1 multi-scalar sums), commitments already at hand; "
+                        "verify_latency_ms: the whole verifier on the serialised proof (plonk_amd/verifier.py: decoding, "
+                        "the commitment of the public-input polynomial, challenges, field equations, the fold)")
         if shared_prover is not None:
             if isinstance(shared_prover, tuple):
                 extras["prove_latency_s"] = round(shared_prover[0], 3)

@@ -98,7 +98,15 @@ def test_proof_of_a_circuit_of_2_to_20_gates():
         assert p.audit_with_tau(tau) >= 2  # every logged commitment / opening equals [f(tau)]G / [q(tau)]G
         assert p.check_identities((circuit.number_gates, circuit.pub_inputs), proof, keys)
         # the openings by pairings, folded into one check (public parameters only)
-        assert p.verify_openings(plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau])[0]))
+        tau_g2 = plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau])[0])
+        assert p.verify_openings(tau_g2)
+        # and the whole verifier on the proof as it is serialised (verifier::run, plonk/src/verifier/mod.rs:13-42)
+        from plonk_amd import verifier
+        vk = {"com_S": p.hex_of(keys["com_S"]), "com_W": p.hex_of(keys["com_W"])}
+        v = verifier.Verifier(be, circuit.d, circuit.number_gates, len(circuit.pub_inputs), tau_g2)
+        assert v.run(vk, proof)
+        forged = dict(proof, output=str((int(proof["output"]) + 1) % pv.R_MOD))
+        assert not v.run(vk, forged)
         p.kzg_log = None
         assert p.prove_resident(circuit, keys) == proof  # deterministic
     finally:
