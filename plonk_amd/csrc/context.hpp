@@ -21,7 +21,7 @@ struct DevBuf {
 
 struct MsmPlan {
     int c = 0;           // bits per window
-    int nwin = 0;        // windows = 255/c + 1
+    int nwin = 0;        // windows = ceil(255 / c)
     uint32_t nbuckets = 0;  // 2^(c-1)
 };
 

@@ -63,13 +63,14 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr k = fe_from_mont(scalars[i]);
+    const bool opposite = scalar_fold(k);  // digits of r - k: every entry takes the opposite point
     uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         int32_t d = signed_digit(k, w, c, carry);
         uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
         // digit 0 contributes nothing: key nbuckets sorts behind every real bucket
         uint32_t key = mag == 0 ? nbuckets : mag - 1;
-        uint32_t val = ((uint32_t)w * srs_n + first + i) | (d < 0 ? 0x80000000u : 0u);
+        uint32_t val = ((uint32_t)w * srs_n + first + i) | (((d < 0) != opposite) ? 0x80000000u : 0u);
         size_t at = (size_t)w * n + i;
         keys[at] = key;
         vals[at] = val;
@@ -704,11 +705,12 @@ MsmPlan msm_choose_plan(size_t srs_n, int override_bits) {
     if (override_bits >= 2 && override_bits <= 24) {
         best = override_bits;
     } else if (srs_n > 1024) {
-        // Measured on MI355X.  Widths whose top window is narrow (255 mod c small) pile that
-        // window's digits into a few buckets and pay for it in the fix-up, hence 13, 16, 20, 22.
+        // Measured on MI355X.  Widths whose top window is narrow (255 mod c small but not 0) pile that
+        // window's digits into a few buckets and pay for it in the fix-up, hence 13, 20, 22 and the two
+        // divisors of 255, whose windows are all full: 15 and 17.
         int lg = 0;
         while (((size_t)1 << lg) < srs_n) lg++;
-        best = lg <= 16 ? 13 : (lg <= 20 ? 16 : (lg <= 23 ? 20 : 22));
+        best = lg <= 13 ? 13 : (lg <= 18 ? 15 : (lg <= 20 ? 17 : (lg <= 23 ? 20 : 22)));
     } else {
         // Small inputs: cost in "bucket additions"; the accumulation runs ~2^18 lanes at once, the
         // reduction is a serial tail whose depth grows with c.

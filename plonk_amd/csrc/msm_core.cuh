@@ -4,9 +4,27 @@
 
 namespace plonk {
 
-// Number of signed c-bit windows that cover a 255-bit scalar and absorb the last carry:
-// floor(255 / c) + 1 leaves at least one spare bit above bit 254 in the top window.
-PLONK_HD constexpr int msm_num_windows(int c) { return 255 / c + 1; }
+// Number of signed c-bit windows: ceil(255 / c).  The digits are taken of k or of r - k, whichever is the
+// smaller (scalar_fold: at most (r - 1) / 2 < 2^254), so the top window -- which reaches bit 254 at least --
+// holds less than 2^(c-1) and its digit never carries out.  (Without the fold a width that divides 255, such
+// as 15 or 17, would need one more window for that carry, with half of all entries in a single bucket.)
+PLONK_HD constexpr int msm_num_windows(int c) { return (255 + c - 1) / c; }
+
+// k (canonical, not in Montgomery form) becomes min(k, r - k); true when it was replaced, in which case the
+// caller uses the opposite point: k P = (r - k)(-P).
+PLONK_HD bool scalar_fold(Fr &k) {
+    const Fr n = fe_neg(k);  // r - k, and 0 for k = 0
+    bool less = false, decided = false;
+#pragma unroll
+    for (int i = FrCfg::N - 1; i >= 0; i--) {
+        if (!decided && n.l[i] != k.l[i]) {
+            less = n.l[i] < k.l[i];
+            decided = true;
+        }
+    }
+    if (less) k = n;
+    return less;
+}
 
 // Signed digit of window w of the canonical (non-Montgomery) scalar k.
 //   raw = bits [w*c, w*c + c) of k, d = raw + carry_in;

@@ -132,17 +132,26 @@ def test_group_law(hc):
 def test_signed_digits_recompose(hc, cbits):
     rnd = random.Random(23 + cbits)
     nwin = hc.hc_num_windows(cbits)
-    assert nwin == 255 // cbits + 1
-    vals = [0, 1, o.R - 1, o.R - 2, (1 << 255) % o.R, (1 << 254) - 1] + [rnd.randrange(o.R) for _ in range(50)]
+    assert nwin == -(-255 // cbits)
+    half_r = (o.R - 1) // 2
+    vals = [0, 1, o.R - 1, o.R - 2, (1 << 255) % o.R, (1 << 254) - 1, half_r, half_r + 1, half_r - 1]
+    vals += [rnd.randrange(o.R) for _ in range(50)]
     half = 1 << (cbits - 1)
     # worst case for carries: every window at its maximum
     vals.append(min(o.R - 1, (1 << 255) - 1))
+    # ... and of the folded scalar: the largest value below (r + 1) / 2 with all low windows full
+    vals.append(half_r - (half_r % (1 << (cbits * (nwin - 2)))) - 1)
     for v in vals:
         sm = np.ascontiguousarray(c.fr_to_mont([v])[0])
         out = np.zeros(nwin, dtype=np.int32)
-        hc.hc_scalar_digits(_p32(sm), cbits, nwin, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        carry = ctypes.c_uint32(7)
+        opposite = hc.hc_scalar_digits(_p32(sm), cbits, nwin, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                       ctypes.byref(carry))
+        assert opposite == (1 if v > half_r else 0)
+        assert carry.value == 0                       # the top window absorbs everything
         assert all(-half < int(d) <= half for d in out)
-        assert sum(int(d) << (cbits * w) for w, d in enumerate(out)) == v
+        # the digits are those of the smaller of v and r - v
+        assert sum(int(d) << (cbits * w) for w, d in enumerate(out)) == (o.R - v if opposite else v)
 
 
 def test_28_bit_limb_form_matches_fq(hc):

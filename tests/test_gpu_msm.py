@@ -19,7 +19,7 @@ def golden_srs(golden):
     return c.g1_to_limbs(setup.gp.tau_powers_g1)
 
 
-@pytest.mark.parametrize("window_bits", [0, 2, 3, 8, 13, 16])
+@pytest.mark.parametrize("window_bits", [0, 2, 3, 8, 13, 15, 16, 17])
 def test_verification_key_commitments(backend, golden, golden_srs, window_bits):
     # com_S (3 coefficients) and com_W (12) of plonk/data/verification_key.json
     backend.set_window_bits(window_bits)
@@ -129,7 +129,7 @@ def test_commit_skewed_buckets_known_answer(backend, log_n):
         assert same_point(backend.kzg_commit(sc), c.g1_mul(g, c.fr_eval(sc, tau))), name
 
 
-@pytest.mark.parametrize("window_bits", [4, 9, 13, 16])
+@pytest.mark.parametrize("window_bits", [4, 9, 13, 15, 17])
 def test_cooperative_sums_meet_identity_equal_and_opposite_operands(backend, window_bits):
     """The tail sums of small bucket arrays run on four cooperating waves whose barrier loops depend on every
     wave taking the same per-slot decisions.  With every SRS point equal to G (tau = 1) and hand-picked
