@@ -196,7 +196,8 @@ int plonk_hip_profile(plonk_hip_ctx *ctx, int enable);
 int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]);
 const char *plonk_hip_msm_phase_name(int i);
 /* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
- * integer multiply-add `v_mad_u64_u32` issued from registers only; measured, takes ~50 ms. */
+ * integer multiply-add `v_mad_u64_u32` issued from registers only, measured after the shader clock has come
+ * up (about 100 ms in all). */
 int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
 /* Issue-cost probe: multiply-add rate with `extra` (0, 1, 2 or 4) cheap integer VALU instructions
  * after every multiply-add, and the shader clock (GHz) the kernel ran at. */
