@@ -5,13 +5,13 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, plonk_amd
 be = plonk_amd.Backend(0)
-for logn in (16, 20, 22):
+for logn in (12, 14, 16, 18, 20, 21, 22):
     n = 1 << logn
     be.kzg_setup(np.array([3, 1, 4, 1], dtype=np.uint64), n - 1, want_points=False)
     sc = np.frombuffer(np.random.default_rng(1).bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy(); sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
     d = be.to_device(sc); out = be.malloc(144)
     res = []
-    for rep in range(5):
+    for rep in range(8):  # the later repetitions run on a warm clock
         be.kzg_commit_dev(d, n, out); be.sync()
         t = time.perf_counter()
         for _ in range(8): be.kzg_commit_dev(d, n, out)

@@ -44,12 +44,15 @@ def kernel_bytes(tag, leg, needle, min_grid=0):
     fetch = pick("_fetch", {"FETCH_SIZE"})
     write = pick("_write", {"WRITE_SIZE"})
     sized = pick("_rdsz", {"TCC_EA0_RDREQ_128B", "TCC_EA0_RDREQ_64B", "TCC_EA0_RDREQ_32B"})
-    if not fetch or len(fetch) != len(write) or len(sized) != len(write):
-        raise SystemExit("launch counts of %s differ in %s: %d / %d / %d" % (needle, base, len(fetch), len(write), len(sized)))
-    wr = sum(v["WRITE_SIZE"] for v in write) * 1024
-    rd_sized = sum(128 * v["TCC_EA0_RDREQ_128B"] + 64 * v["TCC_EA0_RDREQ_64B"] + 32 * v["TCC_EA0_RDREQ_32B"] for v in sized)
-    rd_fetch2 = sum(v["FETCH_SIZE"] for v in fetch) * 2 * 1024
-    return len(write), rd_sized + wr, rd_fetch2 + wr, rd_sized, wr
+    if not fetch or not write or not sized:
+        raise SystemExit("no launches of %s in %s" % (needle, base))
+    # every counter pass is a run of its own and a clock warm-up that lasts a fixed time launches a different
+    # number of kernels in each: per-launch averages pass by pass
+    wr = sum(v["WRITE_SIZE"] for v in write) * 1024 / len(write)
+    rd_sized = sum(128 * v["TCC_EA0_RDREQ_128B"] + 64 * v["TCC_EA0_RDREQ_64B"] + 32 * v["TCC_EA0_RDREQ_32B"]
+                   for v in sized) / len(sized)
+    rd_fetch2 = sum(v["FETCH_SIZE"] for v in fetch) * 2 * 1024 / len(fetch)
+    return min(len(write), len(fetch), len(sized)), rd_sized + wr, rd_fetch2 + wr, rd_sized, wr
 
 
 def main():
@@ -57,15 +60,16 @@ def main():
     entries = {}
     n, total, total_f2, rd, wr = kernel_bytes(tag, "msm", "k_accumulate", min_grid=1 << 16)
     entries["msm_2^24_x1"] = {"k_accumulate": {
-        "bytes": int(total / n), "bytes_by_2x_fetch_size": int(total_f2 / n), "read_bytes": int(rd / n),
-        "write_bytes": int(wr / n), "what": "average over %d launches of one 2^24-point commitment" % n}}
-    # bench.py --workload ntt / quotient --steps 3 --warmup 1: four steps
-    for leg, key, steps in (("ntt", "ntt_16x2^20", 4), ("quo", "quotient_16x2^20", 4)):
+        "bytes": int(total), "bytes_by_2x_fetch_size": int(total_f2), "read_bytes": int(rd),
+        "write_bytes": int(wr), "what": "average over %d launches of one 2^24-point commitment" % n}}
+    # bench.py --workload ntt / quotient: a step is two pass launches (one transform of 2^20 points per polynomial)
+    # or four (two transforms of 2^21 points); the clock warm-up ahead of the timed steps runs the same step
+    for leg, key, per_step in (("ntt", "ntt_16x2^20", 2), ("quo", "quotient_16x2^20", 4)):
         n, total, total_f2, rd, wr = kernel_bytes(tag, leg, "k_ntt_pass")
         entries[key] = {"k_ntt_pass": {
-            "bytes": int(total / steps), "bytes_by_2x_fetch_size": int(total_f2 / steps), "read_bytes": int(rd / steps),
-            "write_bytes": int(wr / steps),
-            "what": "all %d pass launches of %d steps, per step (16 polynomials)" % (n, steps)}}
+            "bytes": int(total * per_step), "bytes_by_2x_fetch_size": int(total_f2 * per_step),
+            "read_bytes": int(rd * per_step), "write_bytes": int(wr * per_step),
+            "what": "average over at least %d pass launches, times the %d launches of a step (16 polynomials)" % (n, per_step)}}
     json.dump({"commit": commit, "tag": tag, "entries": entries}, sys.stdout, indent=1)
     print()
 
