@@ -431,6 +431,52 @@ static int open_many_core(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const uin
     return PLONK_HIP_OK;
 }
 
+// One opening of a long polynomial in host memory, in slices like commit_host_sliced.  The scan
+// s_j = f_j + u s_(j+1) runs from the top, so the slices are copied from the top down (the two short ones
+// first); the scan of a slice takes the value the slice above ended with as one more coefficient behind its
+// own (in the staging buffer that place holds the first coefficient of the slice above, which its scan has
+// consumed by then), and the quotient coefficients s_j, j >= 1, of the slice go into a multi-scalar
+// multiplication against the SRS points from j - 1 on, tail deferred.  v = s_0 comes out of the last scan.
+static int open_host_sliced(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const Fr &u, uint64_t v[4],
+                            uint64_t proof[18]) {
+    const size_t slices = kSliceMax;
+    size_t len_of[kSliceMax];  // from the top: an eighth, an eighth, a quarter, the rest
+    len_of[0] = len_of[1] = n / 8;
+    len_of[2] = n / 4;
+    len_of[3] = n - len_of[0] - len_of[1] - len_of[2];
+    const size_t longest = len_of[3] + 1;
+    PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, (n + 1) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->scratch_c, (longest + suffix_scan_scratch_elems(longest)) * sizeof(Fr)));
+    PLONK_TRY(buf_reserve(ctx, ctx->out_stage, 64 * sizeof(G1Jac) + 4096));
+    Fr *d_f = (Fr *)ctx->scalars_stage.ptr, *d_s = (Fr *)ctx->scratch_c.ptr;
+    G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr, *d_parts = d_out + 1;
+    if (!ctx->copy_stream) PLONK_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // the staging buffer may still be read by kernels of an earlier call
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t end = n;
+    for (size_t k = 0; k < slices; k++) {
+        const size_t len = len_of[k], begin = end - len;
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f + begin, coeffs + 4 * begin, len * sizeof(Fr), hipMemcpyHostToDevice,
+                                          ctx->copy_stream));
+        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+        const size_t carried = k ? 1 : 0;
+        if (carried) {
+            // s_end: the first value of the scan before this one (queued behind it, ahead of this slice's scan)
+            PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f + end, d_s, sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        PLONK_TRY(suffix_scan(ctx, d_f + begin, len + carried, u, d_s, d_s + len + carried));
+        const size_t skip = begin == 0 ? 1 : 0;  // s_0 = f(u) is the value, not a coefficient of the quotient
+        PLONK_TRY(msm_run_dev(ctx, d_s + skip, len - skip, d_parts + k, nullptr, true, begin + skip - 1));
+        end = begin;
+    }
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(v, d_s, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_TRY(msm_join(ctx));
+    PLONK_TRY(g1_sum_dev(ctx, d_parts, slices, d_out));
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(proof, d_out, sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PLONK_HIP_OK;
+}
+
 int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
                             uint64_t *vs, uint64_t *proofs) {
     PLONK_ENTER(ctx);
@@ -438,6 +484,7 @@ int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n
     if (ctx->srs_n == 0) return PLONK_HIP_ERR_NO_SRS;
     if (n < 2) return PLONK_HIP_ERR_EMPTY_POLY;
     if (n - 1 > ctx->srs_n) return PLONK_HIP_ERR_SRS_TOO_SHORT;
+    if (m == 1 && n >= kSliceMax * kSliceMin) return open_host_sliced(ctx, coeffs, n, load_fr(us), vs, proofs);
     PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, n * sizeof(Fr)));
     Fr *d_f = (Fr *)ctx->scalars_stage.ptr;
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(d_f, coeffs, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));

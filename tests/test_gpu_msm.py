@@ -371,6 +371,33 @@ def test_large_host_commit_in_slices_equals_the_resident_commit(backend, n):
     assert same_point(got, c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau)))
 
 
+def test_large_host_opening_in_slices(backend):
+    """kzg_evaluate on 2^24 and more host coefficients copies them in four slices from the top down, scans
+    each with the value carried from the slice above and commits the quotient slice by slice: v = f(u) and
+    the proof [(f(tau) - v) / (tau - u)]G by the oracle's field arithmetic, and the same proof as the
+    one-piece opening of the resident polynomial."""
+    n = (1 << 24) + 777
+    rng = np.random.default_rng(29)
+    tau_int, u_int = 0xFEDCBA + (1 << 180), 0x13579B + (1 << 222)
+    tau, u = c.fr_to_mont([tau_int])[0], c.fr_to_mont([u_int])[0]
+    backend.kzg_setup(tau, n - 2, want_points=False)  # the quotient has n - 1 coefficients
+    sc = np.frombuffer(rng.bytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    v, proof = backend.kzg_evaluate(sc, u)
+    want_v = c.fr_eval(sc, u)
+    assert np.array_equal(np.asarray(v).reshape(4), want_v)
+    f_tau = c.fr_from_mont(c.fr_eval(sc, tau))[0]
+    q_tau = (f_tau - c.fr_from_mont(want_v)[0]) * pow(tau_int - u_int, -1, o.R) % o.R
+    assert same_point(proof, c.g1_mul(c.g1_generator(), c.fr_to_mont([q_tau])[0]))
+    d = backend.to_device(sc)
+    try:
+        vs_dev, proofs_dev = backend.kzg_open_many_dev(d, n, np.asarray(u).reshape(1, 4))
+        assert np.array_equal(vs_dev[0], want_v)
+        assert same_point(proof, proofs_dev[0])
+    finally:
+        backend.free(d)
+
+
 def test_full_kzg_protocol_like_the_reference_test(backend):
     """plonk/tests/kzg_tests.rs:199-227: ten random degrees up to 100: setup, commit, evaluate at a random point,
     verify by pairings -- every step through the library.  (A constant polynomial has an empty quotient: the
