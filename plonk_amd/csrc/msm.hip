@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr k = fe_from_mont(scalars[i]);
-    const bool opposite = scalar_fold(k);  // digits of r - k: every entry takes the opposite point
+    // digits of r - k where the width asks for it: every entry then takes the opposite point
+    const bool opposite = msm_folds_scalars(c) && scalar_fold(k);
     uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) {
         int32_t d = signed_digit(k, w, c, carry);

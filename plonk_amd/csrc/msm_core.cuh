@@ -4,11 +4,14 @@
 
 namespace plonk {
 
-// Number of signed c-bit windows: ceil(255 / c).  The digits are taken of k or of r - k, whichever is the
-// smaller (scalar_fold: at most (r - 1) / 2 < 2^254), so the top window -- which reaches bit 254 at least --
-// holds less than 2^(c-1) and its digit never carries out.  (Without the fold a width that divides 255, such
-// as 15 or 17, would need one more window for that carry, with half of all entries in a single bucket.)
+// Number of signed c-bit windows: ceil(255 / c).  Where c divides 255 (15, 17) this relies on the digits being
+// taken of k or of r - k, whichever is the smaller (scalar_fold: at most (r - 1) / 2 < 2^254): the top window,
+// which ends at bit 254, then holds less than 2^(c-1) and its digit never carries out.  (Without the fold
+// such a width needs one more window for that carry, with half of all entries in a single bucket.)  For every
+// other width the windows reach beyond bit 254 anyway and the scalar is used as it is: folding would halve
+// the range of the narrow top window, i.e. pile its digits into half as many buckets.
 PLONK_HD constexpr int msm_num_windows(int c) { return (255 + c - 1) / c; }
+PLONK_HD constexpr bool msm_folds_scalars(int c) { return 255 % c == 0; }
 
 // k (canonical, not in Montgomery form) becomes min(k, r - k); true when it was replaced, in which case the
 // caller uses the opposite point: k P = (r - k)(-P).

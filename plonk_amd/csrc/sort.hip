@@ -21,7 +21,10 @@ namespace plonk {
 #ifndef PLONK_SORT_ITEMS
 #define PLONK_SORT_ITEMS 32
 #endif
-static constexpr int kSortThreads = 256, kSortItems = PLONK_SORT_ITEMS, kTile = kSortThreads * kSortItems;
+#ifndef PLONK_SORT_THREADS
+#define PLONK_SORT_THREADS 256
+#endif
+static constexpr int kSortThreads = PLONK_SORT_THREADS, kSortItems = PLONK_SORT_ITEMS, kTile = kSortThreads * kSortItems;
 static constexpr int kSortWaves = kSortThreads / 64, kWaveSpan = 64 * kSortItems;
 static constexpr int kMaxBins = 256, kChunkTiles = 128;
 
@@ -31,7 +34,7 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ keys, size_t n, uint32_t shift,
                                                             uint32_t mask, uint32_t *__restrict__ hist) {
     __shared__ uint32_t count[kMaxBins];
-    count[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxBins) count[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * kTile;
     if (base + kTile <= n) {
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
         for (size_t i = base + threadIdx.x; i < n; i += kSortThreads) atomicAdd(&count[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(size_t)blockIdx.x * kMaxBins + threadIdx.x] = count[threadIdx.x];
+    if (threadIdx.x < kMaxBins) hist[(size_t)blockIdx.x * kMaxBins + threadIdx.x] = count[threadIdx.x];
 }
 
 // Level 1: one block per chunk of kChunkTiles tiles, lane b owns bin b: hist[tile][b] becomes the number of
@@ -155,32 +158,36 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
     }
     __syncthreads();
     // per bin: start in the reordered tile, start of every wave's share, destination in the output
+    // (lane b < kMaxBins owns bin b; the other lanes only keep the barriers company)
     {
-        const uint32_t b = t;  // kSortThreads == kMaxBins
+        const uint32_t b = t & (kMaxBins - 1);
+        const bool owner = t < kMaxBins;
         uint32_t c[kSortWaves], total = 0;
 #pragma unroll
         for (int i = 0; i < kSortWaves; i++) {
             c[i] = wave_count[i][b];
             total += c[i];
         }
-        bin_start[b] = total;
+        if (owner) bin_start[b] = total;
         __syncthreads();
         for (uint32_t off = 1; off < kMaxBins; off <<= 1) {
             const uint32_t v = b >= off ? bin_start[b - off] : 0u;
             __syncthreads();
-            bin_start[b] += v;
+            if (owner) bin_start[b] += v;
             __syncthreads();
         }
         const uint32_t start = bin_start[b] - total;
         __syncthreads();
-        bin_start[b] = start;
-        uint32_t run = start;
+        if (owner) {
+            bin_start[b] = start;
+            uint32_t run = start;
 #pragma unroll
-        for (int i = 0; i < kSortWaves; i++) {
-            wave_count[i][b] = run;
-            run += c[i];
+            for (int i = 0; i < kSortWaves; i++) {
+                wave_count[i][b] = run;
+                run += c[i];
+            }
+            bin_dest[b] = chunk_base[(size_t)(blockIdx.x / kChunkTiles) * kMaxBins + b] + hist[(size_t)blockIdx.x * kMaxBins + b];
         }
-        bin_dest[b] = chunk_base[(size_t)(blockIdx.x / kChunkTiles) * kMaxBins + b] + hist[(size_t)blockIdx.x * kMaxBins + b];
     }
     __syncthreads();
 #pragma unroll

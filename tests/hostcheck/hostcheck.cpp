@@ -98,11 +98,11 @@ extern "C" void hc_xyzz_from_affine(const uint32_t *a, uint32_t *out) {
 }
 
 // Signed window digits of a Montgomery-form scalar (see msm_core.cuh).
-// Returns 1 when the digits are those of r - k (the MSM then takes the opposite point), and the carry out of the
-// top window in *carry_out (always 0 for a folded scalar).
+// Returns 1 when the digits are those of r - k (widths that divide 255: the MSM then takes the opposite point),
+// and the carry out of the top window in *carry_out (always 0).
 extern "C" int hc_scalar_digits(const uint32_t *scalar_mont, int c, int nwin, int32_t *out, uint32_t *carry_out) {
     Fr k = fe_from_mont(ld<FrCfg>(scalar_mont));
-    const bool opposite = scalar_fold(k);
+    const bool opposite = msm_folds_scalars(c) && scalar_fold(k);
     uint32_t carry = 0;
     for (int w = 0; w < nwin; w++) out[w] = signed_digit(k, w, c, carry);
     *carry_out = carry;

@@ -147,7 +147,7 @@ def test_signed_digits_recompose(hc, cbits):
         carry = ctypes.c_uint32(7)
         opposite = hc.hc_scalar_digits(_p32(sm), cbits, nwin, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                        ctypes.byref(carry))
-        assert opposite == (1 if v > half_r else 0)
+        assert opposite == (1 if 255 % cbits == 0 and v > half_r else 0)   # only widths that divide 255 fold
         assert carry.value == 0                       # the top window absorbs everything
         assert all(-half < int(d) <= half for d in out)
         # the digits are those of the smaller of v and r - v

@@ -24,7 +24,7 @@ def test_msm_plans_cover_a_255_bit_scalar(lib):
             c, nwin, nb = msm_plan(lib, n)
             assert 2 <= c <= 24
             assert nb == 1 << (c - 1)            # signed digits: magnitudes 1 .. 2^(c-1)
-            assert nwin == -(-255 // c)           # the folded scalar min(k, r - k) < 2^254 never carries out of the top window
+            assert nwin == -(-255 // c)           # windows reach bit 254; widths that divide 255 fold the scalar to min(k, r - k) < 2^254
             assert n * nwin < 1 << 31            # table index + sign bit fit one 32-bit word
     for c in (2, 3, 8, 13, 16, 24):
         assert msm_plan(lib, 1000, c)[0] == c   # explicit override wins
