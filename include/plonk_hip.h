@@ -195,27 +195,7 @@ int plonk_hip_timer_stop(plonk_hip_ctx *ctx, float *ms);
 int plonk_hip_profile(plonk_hip_ctx *ctx, int enable);
 int plonk_hip_msm_phase_ms(plonk_hip_ctx *ctx, float ms[PLONK_HIP_MSM_PHASES]);
 const char *plonk_hip_msm_phase_name(int i);
-/* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
- * integer multiply-add `v_mad_u64_u32` issued from registers only, measured after the shader clock has come
- * up (about 100 ms in all). */
-int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
-/* Issue-cost probe: multiply-add rate with `extra` (0, 1, 2 or 4) cheap integer VALU instructions
- * after every multiply-add, and the shader clock (GHz) the kernel ran at. */
-int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second,
-                             double *clock_ghz);
-/* Sustained Fq Montgomery multiplications per second (whole GPU) of dependent chains in
- * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
-int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
 /* Window plan in force: bits per window, windows, buckets. */
-/* Measured lane-operations/s of one VALU instruction (op: 0 v_lshrrev_b64, 1 v_lshl_add_u64,
- * 2 v_alignbit_b32, 3 v_and_b32, 4 v_add3_u32, 5 v_mad_i64_i32, 6 v_ashrrev_i64, 7 v_mul_lo_u32,
- * 8 v_mad_u64_u32, 9 v_sub_u32): the per-instruction costs behind the kernels' instruction budgets. */
-int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
-/* Measured bytes/s of a random gather of whole 128-byte lines from a table of table_bytes: the
- * memory-side ceiling of the bucket accumulation's table reads.  An odd table_bytes selects the
- * access form the accumulation kernel uses (eight lanes per line, direct global-to-LDS loads);
- * an even one the plain form (every lane reads its own line). */
-int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
 int plonk_hip_msm_plan(plonk_hip_ctx *ctx, int *window_bits, int *windows, size_t *buckets);
 /* Host-only planning, usable without a GPU: the window plan an SRS of srs_n points would get, and
  * the passes of a 2^log_n-point transform (returns the number of passes, stage ranges

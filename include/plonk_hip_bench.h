@@ -1,0 +1,42 @@
+/* plonk_hip_bench.h -- hardware probes of libplonk_hip.so.
+ *
+ * Not part of the surface a binding of the reference needs (that is plonk_hip.h): these entry points measure
+ * the machine -- the integer multiply-add rate that bounds the bucket accumulation and the transforms, the issue
+ * cost of single instructions, the rate of random 128-byte line gathers -- so that a benchmark can state its
+ * roofline against figures taken in the same process.  They have no counterpart in the reference.
+ */
+#ifndef PLONK_HIP_BENCH_H
+#define PLONK_HIP_BENCH_H
+
+#include "plonk_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Roofline denominator: sustained rate (multiply-adds per second, whole GPU) of the 32x32+64
+ * integer multiply-add `v_mad_u64_u32` issued from registers only, measured after the shader clock has come
+ * up (about 100 ms in all). */
+int plonk_hip_bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);
+/* Issue-cost probe: multiply-add rate with `extra` (0, 1, 2 or 4) cheap integer VALU instructions
+ * after every multiply-add, and the shader clock (GHz) the kernel ran at. */
+int plonk_hip_bench_mad_mix(plonk_hip_ctx *ctx, int extra, int blocks_per_cu, double *mads_per_second,
+                             double *clock_ghz);
+/* Sustained Fq Montgomery multiplications per second (whole GPU) of dependent chains in
+ * registers; variant 0 = the form the kernels use, 1 = the portable CIOS form. */
+int plonk_hip_bench_fq_mul_rate(plonk_hip_ctx *ctx, int variant, int blocks_per_cu, double *muls_per_second);
+/* Measured lane-operations/s of one VALU instruction (op: 0 v_lshrrev_b64, 1 v_lshl_add_u64,
+ * 2 v_alignbit_b32, 3 v_and_b32, 4 v_add3_u32, 5 v_mad_i64_i32, 6 v_ashrrev_i64, 7 v_mul_lo_u32,
+ * 8 v_mad_u64_u32, 9 v_sub_u32): the per-instruction costs behind the kernels' instruction budgets. */
+int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
+/* Measured bytes/s of a random gather of whole 128-byte lines from a table of table_bytes: the
+ * memory-side ceiling of the bucket accumulation's table reads.  An odd table_bytes selects the
+ * access form the accumulation kernel uses (eight lanes per line, direct global-to-LDS loads);
+ * an even one the plain form (every lane reads its own line). */
+int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PLONK_HIP_BENCH_H */

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <new>
 
+#include "../../include/plonk_hip_bench.h"
 #include "context.hpp"
 #include "poly.hpp"
 
