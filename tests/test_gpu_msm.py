@@ -129,7 +129,7 @@ def test_commit_skewed_buckets_known_answer(backend, log_n):
         assert same_point(backend.kzg_commit(sc), c.g1_mul(g, c.fr_eval(sc, tau))), name
 
 
-@pytest.mark.parametrize("window_bits", [4, 9, 13, 15, 17])
+@pytest.mark.parametrize("window_bits", [4, 9, 13, 15, 16, 17])
 def test_cooperative_sums_meet_identity_equal_and_opposite_operands(backend, window_bits):
     """The tail sums of small bucket arrays run on four cooperating waves whose barrier loops depend on every
     wave taking the same per-slot decisions.  With every SRS point equal to G (tau = 1) and hand-picked
