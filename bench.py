@@ -665,7 +665,10 @@ def main():
                         "multiplications x %d), x points per launch / average k_accumulate duration (HIP events on "
                         "the library stream); the plan run here uses %d windows of %d bits over pre-shifted copies "
                         "of the SRS, i.e. issues %d multiply-adds per point: `issued` prices the same kernel time "
-                        "at that figure; peak = v_mad_u64_u32 register-only microbenchmark run in this process"
+                        "at that figure; peak = v_mad_u64_u32 register-only microbenchmark run in this process, timed "
+                        "after 80 ms of the same kernel, i.e. at the shader clock the part sustains (records taken "
+                        "before that correction show peaks of 28-31 Tmad/s measured on a rising clock and fractions "
+                        "about a tenth higher for the same kernel times)"
                         % (MADS_PER_POINT, CANONICAL_WINDOWS, FQ_MULS_PER_ADDITION, MADS_PER_FQ_MUL, plan["windows"],
                            plan["window_bits"], issued_per_point),
                 "kernel_ms": round(acc_ms, 3),
