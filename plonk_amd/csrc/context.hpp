@@ -144,9 +144,18 @@ int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out);
 // sort.hip
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs_passes(int end_bit);
-// result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one
+// result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one.
+// first_counts_done: the per-tile bin counts of the first pass are in place already (written by the
+// producer of the keys: see sort_pairs_first_pass).
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-               int end_bit, void *temp, size_t temp_bytes);
+               int end_bit, void *temp, size_t temp_bytes, bool first_counts_done = false);
+// What a producer of the keys needs to leave the first pass's counts behind: a tile is `tile` consecutive
+// pairs, its counts are `bins` 32-bit words at counts + tile_index * bins, bin = key & mask.
+struct SortFirstPass {
+    uint32_t tile, bins, mask;
+    uint32_t *counts;
+};
+SortFirstPass sort_pairs_first_pass(int end_bit, void *temp);
 
 // microbench.hip
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);

@@ -221,8 +221,15 @@ size_t sort_pairs_temp_bytes(size_t n, int end_bit) {
 // Sorts the pairs by the low end_bit key bits.  The passes alternate between the two buffer pairs, starting
 // from (keys_a, vals_a): the result is in (keys_b, vals_b) after an odd number of passes (sort_pairs_passes),
 // in (keys_a, vals_a) after an even one.
+// The first pass sorts by the lowest key bits (the key bits spread evenly over the passes, see sort_pairs).
+SortFirstPass sort_pairs_first_pass(int end_bit, void *temp) {
+    const int npasses = sort_pairs_passes(end_bit);
+    const int bits = npasses ? (end_bit + npasses - 1) / npasses : 0;
+    return SortFirstPass{(uint32_t)kTile, (uint32_t)kMaxBins, (1u << bits) - 1, (uint32_t *)temp};
+}
+
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-               int end_bit, void *temp, size_t temp_bytes) {
+               int end_bit, void *temp, size_t temp_bytes, bool first_counts_done) {
     if (n == 0) return PLONK_HIP_OK;
     if (n >= 0xffffffffull || temp_bytes < sort_pairs_temp_bytes(n, end_bit)) return PLONK_HIP_ERR_INVALID_ARG;
     const uint32_t ntiles = cdiv(n, kTile), nchunks = cdiv(ntiles, kChunkTiles);
@@ -234,8 +241,10 @@ int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t 
         const int bits = (end_bit - shift + (npasses - p) - 1) / (npasses - p);
         const uint32_t *kin = (p & 1) ? keys_b : keys_a, *vin = (p & 1) ? vals_b : vals_a;
         uint32_t *kout = (p & 1) ? keys_a : keys_b, *vout = (p & 1) ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
-                           (1u << bits) - 1, hist);
+        if (p > 0 || !first_counts_done) {
+            hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
+                               (1u << bits) - 1, hist);
+        }
         hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(kMaxBins), 0, ctx->stream, hist, ntiles, chunk_total);
         hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(kMaxBins), 0, ctx->stream, chunk_total, nchunks);
         hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, vin, n,
