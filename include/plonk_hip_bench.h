@@ -34,6 +34,10 @@ int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second);
  * access form the accumulation kernel uses (eight lanes per line, direct global-to-LDS loads);
  * an even one the plain form (every lane reads its own line). */
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second);
+/* How the bucket sort ranks keys on this context's device: 1 = one LDS add-with-return per key (the check made
+ * when the context was created found the lanes of an instruction served in ascending order), 0 = the
+ * ballot form that relies on nothing (the check failed, or PLONK_HIP_SORT_RANK=ballot was set). */
+int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx);
 
 #ifdef __cplusplus
 }

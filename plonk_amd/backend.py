@@ -171,6 +171,12 @@ class Backend:
         self._check(self._lib.plonk_hip_bench_op_rate(self._ctx, op, ctypes.byref(v)))
         return v.value
 
+    def sort_rank_mode(self):
+        """"add" when the bucket sort ranks keys with one LDS add-with-return each (the library checked at
+        context creation that this device serves the lanes of such an instruction in ascending order),
+        "ballot" for the form that relies on nothing."""
+        return "add" if self._lib.plonk_hip_bench_sort_rank_mode(self._ctx) else "ballot"
+
     def bench_gather_rate(self, table_bytes):
         v = ctypes.c_double()
         self._check(self._lib.plonk_hip_bench_gather_rate(self._ctx, table_bytes, ctypes.byref(v)))

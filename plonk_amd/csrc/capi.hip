@@ -100,6 +100,10 @@ int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
     plonk_hip_ctx *ctx = new (std::nothrow) plonk_hip_ctx();
     if (!ctx) return PLONK_HIP_ERR_OUT_OF_MEMORY;
     ctx->device = device;
+    if (const char *fe = std::getenv("PLONK_HIP_FRONT_END")) {
+        if (!std::strcmp(fe, "scalars")) ctx->front_end = kFrontEndScalars;
+        if (!std::strcmp(fe, "pairs")) ctx->front_end = kFrontEndPairs;
+    }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
         delete ctx;
         return PLONK_HIP_ERR_HIP;
@@ -111,6 +115,11 @@ int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
         }
     }
     if (resolve_static_scratch(device, &ctx->static_scratch) != hipSuccess) {
+        plonk_hip_ctx_destroy(ctx);
+        return PLONK_HIP_ERR_HIP;
+    }
+    const char *rank = std::getenv("PLONK_HIP_SORT_RANK");
+    if (!(rank && !std::strcmp(rank, "ballot")) && sort_selftest(ctx) != PLONK_HIP_OK) {
         plonk_hip_ctx_destroy(ctx);
         return PLONK_HIP_ERR_HIP;
     }
@@ -521,6 +530,8 @@ int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) 
     if (!ops_per_second) return PLONK_HIP_ERR_INVALID_ARG;
     return bench_op_rate(ctx, op, ops_per_second);
 }
+
+int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx) { return ctx && ctx->lds_rank_in_lane_order ? 1 : 0; }
 
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
     PLONK_ENTER(ctx);

@@ -25,6 +25,10 @@ struct MsmPlan {
     uint32_t nbuckets = 0;  // 2^(c-1)
 };
 
+enum FrontEnd { kFrontEndAuto = 0, kFrontEndScalars, kFrontEndPairs };
+// from this many scalars on the first sort pass is made from the scalars (where its shape allows)
+static constexpr size_t kFrontEndScalarsMin = (size_t)1 << 22;
+
 enum MsmPhase { PH_DIGITS = 0, PH_SORT, PH_BOUNDS, PH_ACCUM, PH_FIXUP, PH_REDUCE, PH_COUNT };
 
 // One MSM whose tail is still to run (device pointers; bucket arrays are G1Xyzz28, see g1_28.cuh).
@@ -54,6 +58,12 @@ struct plonk_hip_ctx {
     std::string last_error;
     std::recursive_mutex mu;  // serialises the entry points that use this context
     int window_bits_override = 0;
+    // how an MSM gets its sorted (bucket, entry) pairs: by size, or one way always (PLONK_HIP_FRONT_END =
+    // "scalars" / "pairs" when the context is created; for tests and measurements)
+    int front_end = plonk::kFrontEndAuto;
+    // the sort ranks keys with one LDS add-with-return each (checked by sort_selftest when the context is created;
+    // PLONK_HIP_SORT_RANK=ballot keeps the form that relies on nothing)
+    bool lds_rank_in_lane_order = false;
 
     // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form
     // (G1Affine28, 128 B each); level w, point i = [2^(c*w)] P_i at table[w * srs_n + i].
@@ -142,6 +152,8 @@ size_t msm_bucket_bytes();
 int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out);
 
 // sort.hip
+// decides how the scatter kernels rank keys on this device (sets ctx->lds_rank_in_lane_order)
+int sort_selftest(plonk_hip_ctx *ctx);
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs_passes(int end_bit);
 // result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one.
@@ -156,6 +168,13 @@ struct SortFirstPass {
     uint32_t *counts;
 };
 SortFirstPass sort_pairs_first_pass(int end_bit, void *temp);
+// The same sort with the first pass made from the scalars (the pairs of scalar i: window w -> key = |digit| - 1
+// or nbuckets for digit 0, val = w * srs_n + first + i with the sign in bit 31); temp as for
+// sort_pairs(n * nwin pairs); result where sort_pairs leaves it.
+bool sort_pairs_of_scalars_applies(size_t n, int end_bit, int nwin);
+int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, size_t srs_n, size_t first, int c, int nwin,
+                          uint32_t nbuckets, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+                          void *temp, size_t temp_bytes);
 
 // microbench.hip
 int bench_mad_rate(plonk_hip_ctx *ctx, double *mads_per_second);

@@ -908,20 +908,30 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     uint32_t *big_count = (uint32_t *)b_big.ptr, *big_list = big_count + 1;
 
     record(ctx, PH_DIGITS);
-    const SortFirstPass fp = sort_pairs_first_pass(pl.c, ctx->sort_tmp.ptr);
-    // (a block per tile: worth it from about four blocks per CU on -- 2^24 points: digits + sort 4.00 ms instead
-    // of 4.25; at 2^22 it is even, at 2^20 the few long-running blocks cost 0.12 ms)
-    const bool with_counts = n % fp.tile == 0 && n / fp.tile >= 1024 && pl.nwin <= kDigitsHistWindows;
-    if (with_counts) {
-        hipLaunchKernelGGL(k_digits_counts, dim3((unsigned)(n / fp.tile)), dim3(256), (size_t)pl.nwin * fp.bins * 4, st,
-                           d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n, (uint32_t)first, pl.c, pl.nwin, nb, keys_a,
-                           vals_a, fp.tile, fp.bins, fp.mask, fp.counts);
+    // Large inputs: the sort's first pass is made from the scalars themselves, the unsorted pairs never exist
+    // (sort.hip).  Small ones: pairs first, then the sort -- fewer and shorter launches.
+    const bool from_scalars = ctx->front_end != kFrontEndPairs && sort_pairs_of_scalars_applies(n, pl.c, pl.nwin) &&
+                              (ctx->front_end == kFrontEndScalars || n >= kFrontEndScalarsMin);
+    if (from_scalars) {
+        record(ctx, PH_SORT);
+        PLONK_TRY(sort_pairs_of_scalars(ctx, d_scalars, n, ctx->srs_n, first, pl.c, pl.nwin, nb, keys_a, keys_b, vals_a,
+                                        vals_b, ctx->sort_tmp.ptr, tmp_bytes));
     } else {
-        hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
-                           (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
+        const SortFirstPass fp = sort_pairs_first_pass(pl.c, ctx->sort_tmp.ptr);
+        // (a block per tile: worth it from about four blocks per CU on; at 2^20 the few long-running blocks cost
+        // 0.12 ms)
+        const bool with_counts = n % fp.tile == 0 && n / fp.tile >= 1024 && pl.nwin <= kDigitsHistWindows;
+        if (with_counts) {
+            hipLaunchKernelGGL(k_digits_counts, dim3((unsigned)(n / fp.tile)), dim3(256), (size_t)pl.nwin * fp.bins * 4, st,
+                               d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n, (uint32_t)first, pl.c, pl.nwin, nb, keys_a,
+                               vals_a, fp.tile, fp.bins, fp.mask, fp.counts);
+        } else {
+            hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
+                               (uint32_t)ctx->srs_n, (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
+        }
+        record(ctx, PH_SORT);
+        PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes, with_counts));
     }
-    record(ctx, PH_SORT);
-    PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes, with_counts));
     if ((sort_pairs_passes(pl.c) & 1) == 0) {  // an even number of passes ends in the first pair of buffers
         keys_b = keys_a;
         vals_b = vals_a;

@@ -12,9 +12,11 @@
 // The pairs cross HBM twice per pass (plus the keys once more for the counts); with 2^13 pairs per
 // tile and 2^8 bins a run is 128 bytes for uniformly distributed digits.  Skewed inputs (all keys
 // equal) only make the runs longer.
+#include <algorithm>
 #include <cstring>
 
 #include "context.hpp"
+#include "msm_core.cuh"
 
 namespace plonk {
 
@@ -55,49 +57,91 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
     if (threadIdx.x < kMaxBins) hist[(size_t)blockIdx.x * kMaxBins + threadIdx.x] = count[threadIdx.x];
 }
 
-// Level 1: one block per chunk of kChunkTiles tiles, lane b owns bin b: hist[tile][b] becomes the number of
-// keys of bin b in the earlier tiles of the chunk; chunk_total[chunk][b] their number in the whole chunk.
-__global__ __launch_bounds__(kMaxBins) void k_radix_scan_tiles(uint32_t *__restrict__ hist, uint32_t ntiles,
-                                                              uint32_t *__restrict__ chunk_total) {
-    const uint32_t b = threadIdx.x, first = blockIdx.x * kChunkTiles;
-    const uint32_t last = first + kChunkTiles < ntiles ? first + kChunkTiles : ntiles;
-    uint32_t run = 0;
-#pragma unroll 8
-    for (uint32_t t = first; t < last; t++) {
-        uint32_t *p = hist + (size_t)t * kMaxBins + b;
-        const uint32_t c = *p;
-        *p = run;
-        run += c;
+// The two scan levels work on counts laid out as [tile][bins] with bins = 64, 128 or 256.  A block is 256 lanes:
+// 256 / bins groups of `bins` lanes, lane b of a group owns bin b.
+//
+// Level 1: one block per chunk of chunk_tiles = kGroupTiles * groups tiles; group g scans the chunk's g-th run
+// of kGroupTiles tiles: hist[tile][b] becomes the number of keys of bin b in the earlier tiles of the chunk;
+// chunk_total[chunk][b] their number in the whole chunk.
+static constexpr uint32_t kGroupTiles = 128;
+
+// values[i * stride] for i in [first, last) become their exclusive running sum (starting from `run`); returns
+// the total.  Sixteen loads in flight at a time: the loop is bound by memory latency.
+__device__ __forceinline__ uint32_t scan_column(uint32_t *__restrict__ values, uint32_t first, uint32_t last,
+                                                size_t stride, uint32_t run) {
+    for (uint32_t i = first; i < last; i += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = i + j < last ? values[(size_t)(i + j) * stride] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            if (i + j < last) values[(size_t)(i + j) * stride] = run;
+            run += v[j];
+        }
     }
-    chunk_total[(size_t)blockIdx.x * kMaxBins + b] = run;
+    return run;
+}
+__device__ __forceinline__ void add_to_column(uint32_t *__restrict__ values, uint32_t first, uint32_t last, size_t stride,
+                                              uint32_t add) {
+#pragma unroll 16
+    for (uint32_t i = first; i < last; i++) values[(size_t)i * stride] += add;
 }
 
-// Level 2: one block, lane b owns bin b: chunk_total[chunk][b] becomes the position of the first key of bin b
-// of that chunk in the sorted order (all keys of smaller bins, then the earlier chunks' keys of bin b).
-__global__ __launch_bounds__(kMaxBins) void k_radix_scan_chunks(uint32_t *__restrict__ chunk_total, uint32_t nchunks) {
-    __shared__ uint32_t bin_total[kMaxBins];
-    const uint32_t b = threadIdx.x;
-    uint32_t run = 0;
-#pragma unroll 8
-    for (uint32_t c = 0; c < nchunks; c++) {
-        uint32_t *p = chunk_total + (size_t)c * kMaxBins + b;
-        const uint32_t v = *p;
-        *p = run;
-        run += v;
+__global__ __launch_bounds__(256) void k_radix_scan_tiles(uint32_t *__restrict__ hist, uint32_t ntiles, uint32_t bins,
+                                                         uint32_t *__restrict__ chunk_total) {
+    __shared__ uint32_t group_total[256];
+    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = 256 / bins;
+    uint32_t first = (blockIdx.x * groups + g) * kGroupTiles;
+    if (first > ntiles) first = ntiles;
+    const uint32_t last = first + kGroupTiles < ntiles ? first + kGroupTiles : ntiles;
+    const uint32_t run = scan_column(hist + b, first, last, bins, 0u);
+    if (groups == 1) {
+        chunk_total[(size_t)blockIdx.x * bins + b] = run;
+        return;
     }
-    bin_total[b] = run;
+    group_total[t] = run;
     __syncthreads();
-    // exclusive prefix over the bins (256 values: a serial pass by every lane over the values below its own
-    // would do; a logarithmic scan keeps it short)
+    uint32_t before = 0, total = 0;
+    for (uint32_t j = 0; j < groups; j++) {
+        const uint32_t v = group_total[j * bins + b];
+        before += j < g ? v : 0u;
+        total += v;
+    }
+    if (before) add_to_column(hist + b, first, last, bins, before);
+    if (g == 0) chunk_total[(size_t)blockIdx.x * bins + b] = total;
+}
+
+// Level 2: one block: chunk_total[chunk][b] becomes the position of the first key of bin b of that chunk in
+// the sorted order (all keys of smaller bins, then the earlier chunks' keys of bin b).  Group g takes the g-th
+// run of chunks.
+__global__ __launch_bounds__(256) void k_radix_scan_chunks(uint32_t *__restrict__ chunk_total, uint32_t nchunks,
+                                                          uint32_t bins) {
+    __shared__ uint32_t group_total[256];
+    __shared__ uint32_t bin_total[kMaxBins];
+    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = 256 / bins;
+    const uint32_t per_group = (nchunks + groups - 1) / groups;
+    const uint32_t first = g * per_group < nchunks ? g * per_group : nchunks;
+    const uint32_t last = first + per_group < nchunks ? first + per_group : nchunks;
+    const uint32_t run = scan_column(chunk_total + b, first, last, bins, 0u);
+    group_total[t] = run;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t j = 0; j < groups; j++) {
+        const uint32_t v = group_total[j * bins + b];
+        before += j < g ? v : 0u;
+        total += v;
+    }
+    // exclusive prefix of the bin totals (entries from `bins` on are zero; a logarithmic scan keeps it short)
+    bin_total[t] = t < bins ? total : 0u;
+    __syncthreads();
     for (uint32_t off = 1; off < kMaxBins; off <<= 1) {
-        const uint32_t v = b >= off ? bin_total[b - off] : 0u;
+        const uint32_t v = t >= off ? bin_total[t - off] : 0u;
         __syncthreads();
-        bin_total[b] += v;
+        bin_total[t] += v;
         __syncthreads();
     }
-    const uint32_t base = bin_total[b] - run;  // inclusive - own = exclusive
-#pragma unroll 8
-    for (uint32_t c = 0; c < nchunks; c++) chunk_total[(size_t)c * kMaxBins + b] += base;
+    const uint32_t base = bin_total[b] - total + before;  // inclusive - own = exclusive
+    add_to_column(chunk_total + b, first, last, bins, base);
 }
 
 // Lanes of the wave (among those with `valid`) whose digit equals this lane's.
@@ -111,8 +155,124 @@ __device__ __forceinline__ uint64_t same_digit_lanes(uint32_t digit, uint32_t bi
     return m;
 }
 
-// Stable scatter of one tile.  Element e of the tile (global position tile * kTile + e) belongs to wave
-// e / kWaveSpan, round (e % kWaveSpan) / 64, lane e % 64: ranks follow that order.
+// Stable scatter of one tile of WAVES * 64 * ITEMS pairs held in registers, by every lane of a block of
+// WAVES waves (WAVES * 64 >= kMaxBins, WAVES >= kMaxBins / 64).  Element e of the tile belongs to wave e / (64 * ITEMS), round
+// (e % (64 * ITEMS)) / 64, lane e % 64: ranks follow that order.  tile_hist: the tile's row of scanned counts,
+// chunk_row: its chunk's row of bin positions (both `bins`-strided rows).  The shared memory may be used again
+// at once by the next call.
+template <int WAVES, int ITEMS>
+struct ScatterMem {
+    uint32_t wave_count[WAVES][kMaxBins];  // per wave and bin: running count, then start position
+    uint32_t bin_start[kMaxBins];          // first position of the bin in the reordered tile
+    uint32_t bin_dest[kMaxBins];           // where that position goes in the output
+    uint32_t skey[WAVES * 64 * ITEMS], sval[WAVES * 64 * ITEMS];
+};
+
+template <int WAVES, int ITEMS, bool ATOMIC_RANK>
+__device__ __forceinline__ void tile_scatter(ScatterMem<WAVES, ITEMS> &m, const uint32_t (&key)[ITEMS],
+                                             const uint32_t (&val)[ITEMS], uint32_t tile_count, uint32_t shift,
+                                             uint32_t bits, const uint32_t *__restrict__ tile_hist,
+                                             const uint32_t *__restrict__ chunk_row,
+                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    constexpr uint32_t kThreads = WAVES * 64, kSpan = 64 * ITEMS;
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t mask = (1u << bits) - 1;
+    for (uint32_t i = t; i < WAVES * kMaxBins; i += kThreads) (&m.wave_count[0][0])[i] = 0;
+    __syncthreads();
+
+    uint32_t rank[ITEMS];
+    const uint32_t wave_first = w * kSpan;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t e = wave_first + r * 64 + lane;
+        const bool valid = e < tile_count;
+        const uint32_t d = (key[r] >> shift) & mask;
+        if (ATOMIC_RANK) {
+            // one LDS operation: the counter's value before this lane's increment (see k_rank_selftest for the
+            // order of the lanes of one instruction that this relies on)
+            rank[r] = valid ? atomicAdd(&m.wave_count[w][d], 1u) : 0u;
+        } else {
+            const uint64_t same = same_digit_lanes(d, bits, valid);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+            uint32_t prior = 0;
+            if (valid) {
+                prior = m.wave_count[w][d];
+                // the wave's LDS operations complete in program order: every lane of the group has read the count
+                // before its first lane replaces it
+                if (below == 0) m.wave_count[w][d] = prior + (uint32_t)__popcll(same);
+            }
+            rank[r] = prior + below;
+        }
+    }
+    __syncthreads();
+    // per bin: start in the reordered tile, start of every wave's share, destination in the output.  Lane b of
+    // the block's first kMaxBins lanes owns bin b: a prefix sum inside each wave (64 bins) by shuffles, the
+    // waves' totals through LDS.
+    {
+        const uint32_t b = t;
+        const bool owner = t < kMaxBins;
+        uint32_t c[WAVES], total = 0;
+        if (owner) {
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) {
+                c[i] = m.wave_count[i][b];
+                total += c[i];
+            }
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)lane >= off) incl += v;
+        }
+        if (owner && lane == 63) m.bin_start[w] = incl;  // the wave's 64 bins together (read back below)
+        __syncthreads();
+        uint32_t start = incl - total;
+        if (owner) {
+            for (uint32_t j = 0; j < w; j++) start += m.bin_start[j];
+        }
+        __syncthreads();
+        if (owner) {
+            m.bin_start[b] = start;
+            uint32_t run = start;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) {
+                m.wave_count[i][b] = run;
+                run += c[i];
+            }
+            if (b <= mask) m.bin_dest[b] = chunk_row[b] + tile_hist[b];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t e = wave_first + r * 64 + lane;
+        if (e < tile_count) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t pos = m.wave_count[w][d] + rank[r];
+            m.skey[pos] = key[r];
+            m.sval[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < tile_count; i += kThreads) {
+        const uint32_t k = m.skey[i];
+        const uint32_t d = (k >> shift) & mask;
+        const size_t dest = (size_t)m.bin_dest[d] + (i - m.bin_start[d]);
+        keys_out[dest] = k;
+        vals_out[dest] = m.sval[i];
+    }
+}
+
+// Consecutive workgroups go to the eight XCDs in turn, each with an L2 of its own; tiles that follow each other
+// write neighbouring runs of every bin, i.e. halves of the same 128-byte lines.  Numbering the tiles so that an XCD
+// works through a contiguous range lets those lines fill up inside one L2.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t block, uint32_t nblocks) {
+    const uint32_t per = nblocks / 8;
+    return block < 8 * per ? (block % 8) * per + block / 8 : block;
+}
+
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
                                                                const uint32_t *__restrict__ vals_in, size_t n,
                                                                uint32_t shift, uint32_t bits,
@@ -120,102 +280,184 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
                                                                const uint32_t *__restrict__ chunk_base,
                                                                uint32_t *__restrict__ keys_out,
                                                                uint32_t *__restrict__ vals_out) {
-    __shared__ uint32_t wave_count[kSortWaves][kMaxBins];  // per wave and bin: running count, then start position
-    __shared__ uint32_t bin_start[kMaxBins];               // first position of the bin in the reordered tile
-    __shared__ uint32_t bin_dest[kMaxBins];                // where that position goes in the output
-    __shared__ uint32_t skey[kTile], sval[kTile];
-    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t mask = (1u << bits) - 1;
-    const size_t tile_base = (size_t)blockIdx.x * kTile;
+    __shared__ ScatterMem<kSortWaves, kSortItems> mem;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const size_t tile_base = (size_t)tile * kTile;
     const uint32_t tile_count = (uint32_t)(n - tile_base < (size_t)kTile ? n - tile_base : (size_t)kTile);
-    for (uint32_t i = t; i < kSortWaves * kMaxBins; i += kSortThreads) (&wave_count[0][0])[i] = 0;
-    __syncthreads();
-
-    uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
-    const uint32_t wave_first = w * kWaveSpan;
+    uint32_t key[kSortItems], val[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
-        const uint32_t e = wave_first + r * 64 + lane;
+        const uint32_t e = w * kWaveSpan + r * 64 + lane;
         const bool valid = e < tile_count;
         key[r] = valid ? keys_in[tile_base + e] : 0u;
         val[r] = valid ? vals_in[tile_base + e] : 0u;
     }
+    tile_scatter<kSortWaves, kSortItems, ATOMIC_RANK>(mem, key, val, tile_count, shift, bits, hist + (size_t)tile * kMaxBins,
+                                         chunk_base + (size_t)(tile / kChunkTiles) * kMaxBins, keys_out, vals_out);
+}
+
+// ---- first pass straight from the scalars ------------------------------------------------------------------
+// A block takes kDigitTile consecutive scalars; its digits of window w are sort tile w * (n / kDigitTile) + block
+// of the first pass (any numbering of the tiles will do for the first pass of a sort from the lowest digit up;
+// both kernels use this one).  Pair of scalar i and window w: key = |digit| - 1 (nbuckets for digit 0, which
+// sorts behind every bucket), val = w * srs_n + first + i with the digit's sign in bit 31.
+static constexpr int kDigitItems = 8, kDigitWaves = 4, kDigitTile = kDigitWaves * 64 * kDigitItems;
+
+// The next window's pair of a scalar that is shifted down as its windows are used up (the lowest c bits of k
+// are the window; extracting window w from a scalar kept whole costs a chain of selects per limb).
+__device__ __forceinline__ void next_digit_pair(Fr &k, bool opposite, uint32_t &carry, int c, uint32_t nbuckets,
+                                                uint32_t entry, uint32_t &key, uint32_t &val) {
+    int32_t d = (int32_t)((k.l[0] & ((1u << c) - 1)) + carry);
 #pragma unroll
-    for (int r = 0; r < kSortItems; r++) {
-        const uint32_t e = wave_first + r * 64 + lane;
-        const bool valid = e < tile_count;
-        const uint32_t d = (key[r] >> shift) & mask;
-        const uint64_t same = same_digit_lanes(d, bits, valid);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-        uint32_t prior = 0;
-        if (valid) {
-            prior = wave_count[w][d];
-            // the wave's LDS operations complete in program order: every lane of the group has read the count
-            // before its first lane replaces it
-            if (below == 0) wave_count[w][d] = prior + (uint32_t)__popcll(same);
+    for (int i = 0; i + 1 < FrCfg::N; i++) k.l[i] = __builtin_amdgcn_alignbit(k.l[i + 1], k.l[i], (uint32_t)c);
+    k.l[FrCfg::N - 1] >>= c;
+    // the signed digit of msm_core.cuh: d > 2^(c-1) -> d - 2^c and a carry into the next window
+    carry = d > (int32_t)(1u << (c - 1)) ? 1u : 0u;
+    if (carry) d -= (int32_t)(1u << c);
+    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    key = mag == 0 ? nbuckets : mag - 1;
+    val = entry | (((d < 0) != opposite) ? 0x80000000u : 0u);
+}
+
+// counts[(w * (n / kDigitTile) + block) * bins + b] = digits of window w of the block's scalars with key & mask == b
+__global__ __launch_bounds__(kDigitWaves * 64) void k_digits_hist(const Fr *__restrict__ scalars, uint32_t n, int c,
+                                                                  int nwin, uint32_t nbuckets, uint32_t bins,
+                                                                  uint32_t *__restrict__ counts) {
+    extern __shared__ uint32_t count[];  // [nwin][bins]
+    for (uint32_t j = threadIdx.x; j < (uint32_t)nwin * bins; j += blockDim.x) count[j] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kDigitTile, mask = bins - 1;
+    Fr raw[kDigitItems];
+#pragma unroll
+    for (int r = 0; r < kDigitItems; r++) raw[r] = scalars[base + r * (kDigitWaves * 64) + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < kDigitItems; r++) {
+        Fr k = fe_from_mont(raw[r]);
+        const bool opposite = msm_folds_scalars(c) && scalar_fold(k);
+        uint32_t carry = 0, key, val;
+        for (int w = 0; w < nwin; w++) {
+            next_digit_pair(k, opposite, carry, c, nbuckets, 0u, key, val);
+            atomicAdd(&count[(uint32_t)w * bins + (key & mask)], 1u);
         }
-        rank[r] = prior + below;
     }
     __syncthreads();
-    // per bin: start in the reordered tile, start of every wave's share, destination in the output
-    // (lane b < kMaxBins owns bin b; the other lanes only keep the barriers company)
-    {
-        const uint32_t b = t & (kMaxBins - 1);
-        const bool owner = t < kMaxBins;
-        uint32_t c[kSortWaves], total = 0;
+    const uint32_t tiles_per_window = n / kDigitTile;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)nwin * bins; j += blockDim.x) {
+        const uint32_t w = j / bins, b = j % bins;
+        counts[((size_t)w * tiles_per_window + blockIdx.x) * bins + b] = count[j];
+    }
+}
+
+template <bool ATOMIC_RANK>
+__global__ __launch_bounds__(kDigitWaves * 64) void k_digits_scatter(const Fr *__restrict__ scalars, uint32_t n,
+                                                                     uint32_t srs_n, uint32_t first, int c, int nwin,
+                                                                     uint32_t nbuckets, uint32_t bits,
+                                                                     const uint32_t *__restrict__ hist,
+                                                                     const uint32_t *__restrict__ chunk_base,
+                                                                     uint32_t chunk_tiles,
+                                                                     uint32_t *__restrict__ keys_out,
+                                                                     uint32_t *__restrict__ vals_out) {
+    __shared__ ScatterMem<kDigitWaves, kDigitItems> mem;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bins = 1u << bits;
+    const uint32_t tiles_per_window = n / kDigitTile, block = xcd_contiguous(blockIdx.x, gridDim.x);
+    Fr k[kDigitItems];
+    uint32_t carry[kDigitItems], index[kDigitItems];
+    bool opposite[kDigitItems];
 #pragma unroll
-        for (int i = 0; i < kSortWaves; i++) {
-            c[i] = wave_count[i][b];
-            total += c[i];
-        }
-        if (owner) bin_start[b] = total;
-        __syncthreads();
-        for (uint32_t off = 1; off < kMaxBins; off <<= 1) {
-            const uint32_t v = b >= off ? bin_start[b - off] : 0u;
-            __syncthreads();
-            if (owner) bin_start[b] += v;
-            __syncthreads();
-        }
-        const uint32_t start = bin_start[b] - total;
-        __syncthreads();
-        if (owner) {
-            bin_start[b] = start;
-            uint32_t run = start;
+    for (int r = 0; r < kDigitItems; r++) {
+        index[r] = block * kDigitTile + wave * (64 * kDigitItems) + r * 64 + lane;
+        k[r] = fe_from_mont(scalars[index[r]]);
+        opposite[r] = msm_folds_scalars(c) && scalar_fold(k[r]);
+        carry[r] = 0;
+    }
+    for (int w = 0; w < nwin; w++) {
+        uint32_t key[kDigitItems], val[kDigitItems];
 #pragma unroll
-            for (int i = 0; i < kSortWaves; i++) {
-                wave_count[i][b] = run;
-                run += c[i];
+        for (int r = 0; r < kDigitItems; r++)
+            next_digit_pair(k[r], opposite[r], carry[r], c, nbuckets, (uint32_t)w * srs_n + first + index[r], key[r], val[r]);
+        const size_t tile = (size_t)w * tiles_per_window + block;
+        tile_scatter<kDigitWaves, kDigitItems, ATOMIC_RANK>(mem, key, val, kDigitTile, 0u, bits, hist + tile * bins,
+                                               chunk_base + (tile / chunk_tiles) * bins, keys_out, vals_out);
+    }
+}
+
+// ---- which ranking the scatter kernels use -----------------------------------------------------------------
+// A stable rank needs, for lanes of one wave that hold the same digit, "how many lower lanes hold it too".  One
+// LDS add-with-return per lane on a counter per digit gives exactly that IF the lanes of one instruction that
+// hit the same counter are served in ascending lane order -- which this part does, but which no manual
+// promises.  So it is checked, once per context: a wave ranks pseudo-random digits of every width both ways
+// (the ballot form above, which relies on nothing, and the add-with-return form); the context uses the
+// one-instruction form only if all ranks agree, and the ballot form (about 50 vector instructions per key
+// instead of one LDS operation) otherwise.
+__global__ __launch_bounds__(64) void k_rank_selftest(uint32_t *__restrict__ mismatches) {
+    __shared__ uint32_t by_ballot[kMaxBins], by_add[kMaxBins];
+    const uint32_t lane = threadIdx.x;
+    uint32_t bad = 0;
+    for (uint32_t bits = 0; bits <= 8; bits++) {
+        for (uint32_t i = lane; i < (uint32_t)kMaxBins; i += 64) by_ballot[i] = by_add[i] = 0;
+        __syncthreads();
+        for (uint32_t round = 0; round < 24; round++) {
+            uint32_t h = (lane * 2654435761u) ^ (round * 40503u + bits * 977u);
+            h ^= h >> 13;
+            h *= 0x5bd1e995u;
+            h ^= h >> 15;
+            const uint32_t d = h & ((1u << bits) - 1);
+            const bool valid = round % 5 != 4 || lane % 3 != 1;  // some rounds with idle lanes
+            const uint64_t same = same_digit_lanes(d, bits, valid);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+            uint32_t want = 0, got = 0;
+            if (valid) {
+                const uint32_t prior = by_ballot[d];
+                if (below == 0) by_ballot[d] = prior + (uint32_t)__popcll(same);
+                want = prior + below;
+                got = atomicAdd(&by_add[d], 1u);
             }
-            bin_dest[b] = chunk_base[(size_t)(blockIdx.x / kChunkTiles) * kMaxBins + b] + hist[(size_t)blockIdx.x * kMaxBins + b];
+            bad += want != got;
         }
+        __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kSortItems; r++) {
-        const uint32_t e = wave_first + r * 64 + lane;
-        if (e < tile_count) {
-            const uint32_t d = (key[r] >> shift) & mask;
-            const uint32_t pos = wave_count[w][d] + rank[r];
-            skey[pos] = key[r];
-            sval[pos] = val[r];
-        }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int sort_selftest(plonk_hip_ctx *ctx) {
+    uint32_t *d_bad = nullptr, bad = 1;
+    PLONK_HIP_TRY(ctx, hipMalloc(&d_bad, 4));
+    hipError_t e = hipMemsetAsync(d_bad, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rank_selftest, dim3(4), dim3(64), 0, ctx->stream, d_bad);
+        e = hipGetLastError();
     }
-    __syncthreads();
-    for (uint32_t i = t; i < tile_count; i += kSortThreads) {
-        const uint32_t k = skey[i];
-        const uint32_t d = (k >> shift) & mask;
-        const size_t dest = (size_t)bin_dest[d] + (i - bin_start[d]);
-        keys_out[dest] = k;
-        vals_out[dest] = sval[i];
-    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_bad);
+    PLONK_HIP_TRY(ctx, e);
+    ctx->lds_rank_in_lane_order = bad == 0;
+    return PLONK_HIP_OK;
 }
 
 int sort_pairs_passes(int end_bit) { return end_bit <= 0 ? 0 : (end_bit + 7) / 8; }
 
+// Key bits of the first pass when it is made from the scalars: as few as leave the later passes at most eight
+// bits each (small tiles: few bins keep the runs written out long), at least six.
+static int fused_first_bits(int end_bit) {
+    const int later = sort_pairs_passes(end_bit) - 1;
+    return std::max(6, end_bit - 8 * later);
+}
+
+bool sort_pairs_of_scalars_applies(size_t n, int end_bit, int nwin) {
+    return n > 0 && n % kDigitTile == 0 && end_bit >= 1 && fused_first_bits(end_bit) <= 8 &&
+           (size_t)nwin * (1u << fused_first_bits(end_bit)) * 4 <= 48 * 1024 && n * (size_t)nwin < 0xffffffffull;
+}
+
 size_t sort_pairs_temp_bytes(size_t n, int end_bit) {
-    (void)end_bit;
     const size_t ntiles = (n + kTile - 1) / kTile, nchunks = (ntiles + kChunkTiles - 1) / kChunkTiles;
-    return (ntiles + nchunks) * kMaxBins * sizeof(uint32_t) + 256;
+    size_t words = (ntiles + nchunks) * kMaxBins;
+    // first pass from the scalars: smaller tiles, rows of 2^bits counts
+    const size_t bins = (size_t)1 << std::min(8, fused_first_bits(end_bit));
+    const size_t dtiles = (n + kDigitTile - 1) / kDigitTile, dchunks = dtiles / kGroupTiles + 1;
+    words = std::max(words, (dtiles + dchunks) * bins);
+    return words * sizeof(uint32_t) + 256;
 }
 
 // Sorts the pairs by the low end_bit key bits.  The passes alternate between the two buffer pairs, starting
@@ -228,29 +470,62 @@ SortFirstPass sort_pairs_first_pass(int end_bit, void *temp) {
     return SortFirstPass{(uint32_t)kTile, (uint32_t)kMaxBins, (1u << bits) - 1, (uint32_t *)temp};
 }
 
+// Passes first_pass .. npasses - 1 over pairs of whole-tile lists; key bits [shift, end_bit) spread evenly.
+static void later_passes(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+                         size_t n, int shift, int end_bit, int first_pass, int npasses, void *temp,
+                         bool first_counts_done) {
+    const uint32_t ntiles = cdiv(n, kTile), nchunks = cdiv(ntiles, kChunkTiles);
+    uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * kMaxBins;
+    for (int p = first_pass; p < npasses; p++) {
+        const int bits = (end_bit - shift + (npasses - p) - 1) / (npasses - p);
+        const uint32_t *kin = (p & 1) ? keys_b : keys_a, *vin = (p & 1) ? vals_b : vals_a;
+        uint32_t *kout = (p & 1) ? keys_a : keys_b, *vout = (p & 1) ? vals_a : vals_b;
+        if (p > first_pass || !first_counts_done) {
+            hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
+                               (1u << bits) - 1, hist);
+        }
+        hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(256), 0, ctx->stream, hist, ntiles, (uint32_t)kMaxBins,
+                           chunk_total);
+        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, ctx->stream, chunk_total, nchunks,
+                           (uint32_t)kMaxBins);
+        hipLaunchKernelGGL(ctx->lds_rank_in_lane_order ? k_radix_scatter<true> : k_radix_scatter<false>, dim3(ntiles),
+                           dim3(kSortThreads), 0, ctx->stream, kin, vin, n, (uint32_t)shift, (uint32_t)bits, hist,
+                           chunk_total, kout, vout);
+        shift += bits;
+    }
+}
+
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
                int end_bit, void *temp, size_t temp_bytes, bool first_counts_done) {
     if (n == 0) return PLONK_HIP_OK;
     if (n >= 0xffffffffull || temp_bytes < sort_pairs_temp_bytes(n, end_bit)) return PLONK_HIP_ERR_INVALID_ARG;
-    const uint32_t ntiles = cdiv(n, kTile), nchunks = cdiv(ntiles, kChunkTiles);
-    uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * kMaxBins;
-    const int npasses = sort_pairs_passes(end_bit);
-    int shift = 0;
-    for (int p = 0; p < npasses; p++) {
-        // the key bits spread evenly over the passes
-        const int bits = (end_bit - shift + (npasses - p) - 1) / (npasses - p);
-        const uint32_t *kin = (p & 1) ? keys_b : keys_a, *vin = (p & 1) ? vals_b : vals_a;
-        uint32_t *kout = (p & 1) ? keys_a : keys_b, *vout = (p & 1) ? vals_a : vals_b;
-        if (p > 0 || !first_counts_done) {
-            hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
-                               (1u << bits) - 1, hist);
-        }
-        hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(kMaxBins), 0, ctx->stream, hist, ntiles, chunk_total);
-        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(kMaxBins), 0, ctx->stream, chunk_total, nchunks);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, vin, n,
-                           (uint32_t)shift, (uint32_t)bits, hist, chunk_total, kout, vout);
-        shift += bits;
-    }
+    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, n, 0, end_bit, 0, sort_pairs_passes(end_bit), temp,
+                 first_counts_done);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+// The sorted (bucket, entry) pairs of n scalars (sort_pairs_of_scalars_applies), in the buffers sort_pairs would
+// leave them in; the first pass writes to (keys_b, vals_b) what it makes of the scalars.
+int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, size_t srs_n, size_t first, int c, int nwin,
+                          uint32_t nbuckets, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+                          void *temp, size_t temp_bytes) {
+    const size_t total = n * (size_t)nwin;
+    if (!sort_pairs_of_scalars_applies(n, c, nwin) || temp_bytes < sort_pairs_temp_bytes(total, c))
+        return PLONK_HIP_ERR_INVALID_ARG;
+    const int bits = fused_first_bits(c), npasses = sort_pairs_passes(c);
+    const uint32_t bins = 1u << bits, groups = 256 / bins, chunk_tiles = kGroupTiles * groups;
+    const uint32_t blocks = (uint32_t)(n / kDigitTile), ntiles = blocks * (uint32_t)nwin, nchunks = cdiv(ntiles, chunk_tiles);
+    uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * bins;
+    hipLaunchKernelGGL(k_digits_hist, dim3(blocks), dim3(kDigitWaves * 64), (size_t)nwin * bins * 4, ctx->stream, d_scalars,
+                       (uint32_t)n, c, nwin, nbuckets, bins, hist);
+    hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(256), 0, ctx->stream, hist, ntiles, bins, chunk_total);
+    hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, ctx->stream, chunk_total, nchunks, bins);
+    hipLaunchKernelGGL(ctx->lds_rank_in_lane_order ? k_digits_scatter<true> : k_digits_scatter<false>, dim3(blocks),
+                       dim3(kDigitWaves * 64), 0, ctx->stream, d_scalars, (uint32_t)n,
+                       (uint32_t)srs_n, (uint32_t)first, c, nwin, nbuckets, (uint32_t)bits, hist, chunk_total, chunk_tiles,
+                       keys_b, vals_b);
+    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, total, bits, c, 1, npasses, temp, false);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }

@@ -416,3 +416,45 @@ def test_full_kzg_protocol_like_the_reference_test(backend):
     backend.kzg_setup(c.fr_to_mont([5])[0], 0, want_points=False)
     with pytest.raises(plonk_amd.ReferencePanic):
         backend.kzg_evaluate(c.fr_to_mont([7]), c.fr_to_mont([3])[0])
+
+
+@pytest.mark.parametrize("window_bits", [0, 3, 6, 7, 8, 9, 13, 15, 16, 17, 20, 22, 23])
+def test_first_sort_pass_made_from_the_scalars(window_bits, monkeypatch):
+    """Large commitments take the first pass of their bucket sort straight from the scalars; a context created with
+    PLONK_HIP_FRONT_END=scalars does so at every size whose shape allows it (a multiple of 2048 scalars).  The
+    result must be the point the pairs-then-sort path gives, and [f(tau)]G (plonk/tests/kzg_tests.rs:36-69),
+    for uniform, repeated, zero and r - 1 scalars, and for a shorter polynomial; and the same point again when the
+    sort ranks its keys by ballots (PLONK_HIP_SORT_RANK=ballot) instead of LDS adds."""
+    rnd = random.Random(900 + window_bits)
+    n = 3 * 2048
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    g = c.g1_generator()
+    s = rnd.randrange(o.R)
+    cases = {
+        "uniform": rand_fr(rnd, n),
+        "equal": [s] * n,
+        "edge": [(0, 1, o.R - 1, (o.R - 1) // 2, (o.R + 1) // 2, 1 << 254, s)[i % 7] for i in range(n)],
+        "sparse": [rnd.randrange(o.R) if i % 16 else 0 for i in range(n)],
+    }
+    results = {}
+    for mode in ("scalars", "pairs", "ballot"):
+        # third run: the first pass from the scalars again, keys ranked by ballots instead of LDS adds
+        monkeypatch.setenv("PLONK_HIP_FRONT_END", "scalars" if mode == "ballot" else mode)
+        monkeypatch.setenv("PLONK_HIP_SORT_RANK", "ballot" if mode == "ballot" else "")
+        be = plonk_amd.Backend(device=0)
+        assert mode != "ballot" or be.sort_rank_mode() == "ballot"
+        try:
+            be.set_window_bits(window_bits)
+            be.kzg_setup(tau, n + 99, want_points=False)
+            for name, vals in cases.items():
+                sc = c.fr_to_mont(vals)
+                results[mode, name] = compress(be.kzg_commit(sc))
+                results[mode, name, "short"] = compress(be.kzg_commit(sc[:2048]))
+        finally:
+            be.close()
+    for name, vals in cases.items():
+        sc = c.fr_to_mont(vals)
+        for other in ("pairs", "ballot"):
+            assert results["scalars", name] == results[other, name], (name, other)
+            assert results["scalars", name, "short"] == results[other, name, "short"], (name, other)
+        assert results["scalars", name] == compress(c.g1_mul(g, c.fr_eval(sc, tau))), name
