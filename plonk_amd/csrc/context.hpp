@@ -27,7 +27,7 @@ struct MsmPlan {
 
 enum FrontEnd { kFrontEndAuto = 0, kFrontEndScalars, kFrontEndPairs };
 // from this many scalars on the first sort pass is made from the scalars (where its shape allows)
-static constexpr size_t kFrontEndScalarsMin = (size_t)1 << 22;
+static constexpr size_t kFrontEndScalarsMin = (size_t)1 << 21;
 
 enum MsmPhase { PH_DIGITS = 0, PH_SORT, PH_BOUNDS, PH_ACCUM, PH_FIXUP, PH_REDUCE, PH_COUNT };
 
