@@ -1,5 +1,5 @@
 // A compiled host program on plonk_hip.hpp: the shape of plonk/tests/kzg_tests.rs (setup, commit, open, verify,
-// SRS too short) plus an interpolation round trip.  Input on the command line: the trapdoor and the point
+// SRS too short) plus an interpolation round trip and the polynomial helpers under the reference's names.  Input on the command line: the trapdoor and the point
 // as 4 limbs each (Montgomery form, hex), then the coefficients as raw limbs on stdin.  Prints the
 // compressed commitment, the opened value (limbs) and the compressed proof as hex lines; the test harness
 // compares them with the oracle.
@@ -53,6 +53,24 @@ int main(int argc, char **argv) {
         back.resize(f.size());
         std::printf("roundtrip %s\n", back == f ? "ok" : "MISMATCH");
         std::printf("verify %s\n", verified ? "ok" : "FAILED");
+        // the polynomial layer under the reference's names: Z = prod (X - r_i) over the first coefficients taken
+        // as roots vanishes on them, (f * Z) / Z gives f back (protocols.rs:169-181), the interpolation through
+        // (r_i, f(r_i)) is f again when f is that short (polynomials.rs:14-58), and f(wX) at u equals f at w u
+        // (polynomials.rs:80-113)
+        const size_t m = f.size() < 24 ? f.size() : 24;
+        const std::vector<Fr> roots(f.begin(), f.begin() + m);
+        const DensePolynomial z = construct_vanishing_polynomial_from_roots(gp, roots);
+        bool poly_ok = z.size() == m + 1;
+        for (const Fr &r : roots) poly_ok = poly_ok && evaluate(gp, z, r) == Fr{0, 0, 0, 0};
+        DensePolynomial q = compute_q_zero_test_from_roots(gp, roots, multiply(gp, f, z));
+        poly_ok = poly_ok && q == f;
+        const DensePolynomial low(f.begin(), f.begin() + m);
+        std::vector<Fr> ys;
+        for (const Fr &r : roots) ys.push_back(evaluate(gp, low, r));
+        poly_ok = poly_ok && interpolate_polynomial(gp, roots, ys) == low;
+        const Fr wu = multiply(gp, {tau}, {u})[0];  // tau * u as a product of constants
+        poly_ok = poly_ok && evaluate(gp, compose_with_scaled_argument(gp, f, tau), u) == evaluate(gp, f, wu);
+        std::printf("polynomials %s\n", poly_ok ? "ok" : "MISMATCH");
         // plonk/tests/kzg_tests.rs:71-93: a polynomial longer than the SRS is a CommitError
         DensePolynomial too_long(degree + 2, Fr{1, 0, 0, 0});
         try {

@@ -7,6 +7,11 @@
 //   kzg_evaluate(gp, f, u)       kzg.rs:63-88                       -> (Fr, G1)
 //   interpolate_over_omega(ys)   plonk/src/common/polynomials.rs:50-58 with x = construct_Omega(n)
 //   compute_q_zero_test(k, f)    plonk/src/common/protocols.rs:157-166
+//   interpolate_polynomial(xs, ys)                      polynomials.rs:14-58, any points
+//   compose_with_scaled_argument(f, w)                  polynomials.rs:80-113 as the gadgets call it: f(wX)
+//   construct_vanishing_polynomial_from_roots(roots)    plonk/src/common/utils.rs:51-62
+//   compute_q_zero_test_from_roots(roots, f)            protocols.rs:169-181
+//   multiply(a, b), evaluate(f, u)                      `&a * &b`, `f.evaluate(&u)`
 //
 // Fr is ark-ff's in-memory form (4 x u64 Montgomery limbs), G1 ark-ec's G1Projective (18 x u64).
 // Where the reference returns Err the wrapper throws CommitError; where the reference panics it throws
@@ -153,6 +158,56 @@ inline std::vector<Fr> evaluate_over_omega(const GlobalParameters &gp, DensePoly
 inline DensePolynomial compute_q_zero_test(const GlobalParameters &gp, size_t k, const DensePolynomial &f) {
     DensePolynomial q(f.size() > k ? f.size() - k : 0);
     if (!q.empty()) gp.check(plonk_hip_fr_div_vanishing(gp.ctx(), f[0].data(), f.size(), k, q[0].data()));
+    return q;
+}
+
+// interpolate_polynomial(x_points, y_points) (polynomials.rs:14-58): the polynomial of degree below n through n
+// points; two equal x are a ReferencePanic (the reference's `.inverse().unwrap()`, polynomials.rs:42)
+inline DensePolynomial interpolate_polynomial(const GlobalParameters &gp, const std::vector<Fr> &xs,
+                                              const std::vector<Fr> &ys) {
+    if (xs.size() != ys.size()) throw Error(PLONK_HIP_ERR_INVALID_ARG, plonk_hip_strerror(PLONK_HIP_ERR_INVALID_ARG));
+    DensePolynomial out(xs.size());
+    if (!xs.empty()) gp.check(plonk_hip_fr_interpolate(gp.ctx(), xs[0].data(), ys[0].data(), xs.size(), out[0].data()));
+    return out;
+}
+
+// compose_polynomials(f, [0, w]) (polynomials.rs:80-113; the only inner polynomial the gadgets use,
+// protocols.rs:258-270 and the like): f(wX)
+inline DensePolynomial compose_with_scaled_argument(const GlobalParameters &gp, DensePolynomial f, const Fr &w) {
+    if (!f.empty()) gp.check(plonk_hip_fr_scale_by_powers(gp.ctx(), f[0].data(), f.size(), w.data()));
+    return f;
+}
+
+// f.evaluate(&u)
+inline Fr evaluate(const GlobalParameters &gp, const DensePolynomial &f, const Fr &u) {
+    Fr out{0, 0, 0, 0};
+    if (!f.empty()) gp.check(plonk_hip_fr_eval(gp.ctx(), f[0].data(), f.size(), u.data(), out.data()));
+    return out;
+}
+
+// &a * &b (untrimmed: a.size() + b.size() - 1 coefficients)
+inline DensePolynomial multiply(const GlobalParameters &gp, const DensePolynomial &a, const DensePolynomial &b) {
+    if (a.empty() || b.empty()) return {};
+    DensePolynomial out(a.size() + b.size() - 1);
+    gp.check(plonk_hip_fr_poly_mul(gp.ctx(), a[0].data(), a.size(), b[0].data(), b.size(), out[0].data()));
+    return out;
+}
+
+// construct_vanishing_polynomial_from_roots(roots) (utils.rs:51-62): prod (X - roots[i])
+inline DensePolynomial construct_vanishing_polynomial_from_roots(const GlobalParameters &gp, const std::vector<Fr> &roots) {
+    DensePolynomial z(roots.size() + 1);
+    gp.check(plonk_hip_fr_vanishing_from_roots(gp.ctx(), roots.empty() ? nullptr : roots[0].data(), roots.size(),
+                                               z[0].data()));
+    return z;
+}
+
+// compute_q_zero_test_from_roots(roots, f) (protocols.rs:169-181): f / prod (X - roots[i]), remainder dropped
+inline DensePolynomial compute_q_zero_test_from_roots(const GlobalParameters &gp, const std::vector<Fr> &roots,
+                                                      const DensePolynomial &f) {
+    DensePolynomial q(f.size() > roots.size() ? f.size() - roots.size() : 0);
+    if (!q.empty())
+        gp.check(plonk_hip_fr_div_by_roots(gp.ctx(), f[0].data(), f.size(), roots.empty() ? nullptr : roots[0].data(),
+                                           roots.size(), q[0].data()));
     return q;
 }
 

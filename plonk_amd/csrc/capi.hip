@@ -345,9 +345,10 @@ static int commit_host_sliced(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t
     // Slice lengths: the GPU idles during the first copy only, so with four slices the first two are short
     // (an eighth each, then a quarter and a half: every copy is shorter than the MSM it hides behind).
     size_t len_of[kSliceMax];
+    // (whole multiples of 2048 except for the last: the length the sort's first pass from the scalars asks for)
     if (slices == kSliceMax) {
-        len_of[0] = len_of[1] = n / 8;
-        len_of[2] = n / 4;
+        len_of[0] = len_of[1] = (n / 8) & ~(size_t)2047;
+        len_of[2] = (n / 4) & ~(size_t)2047;
         len_of[3] = n - len_of[0] - len_of[1] - len_of[2];
     } else {
         const size_t each = (n + slices - 1) / slices;
@@ -450,9 +451,9 @@ static int open_many_core(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const uin
 static int open_host_sliced(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const Fr &u, uint64_t v[4],
                             uint64_t proof[18]) {
     const size_t slices = kSliceMax;
-    size_t len_of[kSliceMax];  // from the top: an eighth, an eighth, a quarter, the rest
-    len_of[0] = len_of[1] = n / 8;
-    len_of[2] = n / 4;
+    size_t len_of[kSliceMax];  // from the top: an eighth, an eighth, a quarter (whole multiples of 2048), the rest
+    len_of[0] = len_of[1] = (n / 8) & ~(size_t)2047;
+    len_of[2] = (n / 4) & ~(size_t)2047;
     len_of[3] = n - len_of[0] - len_of[1] - len_of[2];
     const size_t longest = len_of[3] + 1;
     PLONK_TRY(buf_reserve(ctx, ctx->scalars_stage, (n + 1) * sizeof(Fr)));

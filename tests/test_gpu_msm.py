@@ -343,8 +343,9 @@ def test_compiled_host_program_on_the_cpp_wrapper(backend):
     assert lines[3] == c.g1_compress(want.reshape(1, 18))[0].hex()
     assert lines[4] == "roundtrip ok"
     assert lines[5] == "verify ok"
-    assert lines[6].startswith("commit_error ") and "MISSING" not in lines[6]
-    assert lines[7] == "panic ok"
+    assert lines[6] == "polynomials ok"
+    assert lines[7].startswith("commit_error ") and "MISSING" not in lines[7]
+    assert lines[8] == "panic ok"
 
 
 @pytest.mark.parametrize("n", [(1 << 23) + 12345, (1 << 24) + 777])
