@@ -75,8 +75,11 @@ def gather_partials(local_pt, gathered=None, group=None):
 def commit_sharded(be, d_scalars, n_local, local_pt, gathered, total_pt, group=None):
     """One sharded commitment step on a GPU rank: local MSM (library stream) -> all_gather of the
     partials -> sum on rank 0 into total_pt.  All tensors live on this rank's GPU."""
-    be.kzg_commit_dev(d_scalars, n_local, local_pt.data_ptr())
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        # local_pt may still be read by the gather of the step before (it runs when the slowest rank arrives)
+        torch_then_library(be)
+    be.kzg_commit_dev(d_scalars, n_local, local_pt.data_ptr())
     if world == 1:
         return local_pt
     library_then_torch(be)  # the collective runs on torch's stream
@@ -121,6 +124,7 @@ def commit_sharded_buckets(be, d_scalars, n_local, send, recv, local_pt, gathere
     rank = dist.get_rank(group)
     nbuckets, _ = be.msm_bucket_layout()
     first, count = bucket_slice(nbuckets, world, rank)
+    torch_then_library(be)  # send / local_pt may still be read by the exchanges of the step before
     be.msm_buckets_dev(d_scalars, n_local, send.data_ptr())
     library_then_torch(be)  # the collectives run on torch's stream
     exchange_bucket_slices(send, recv, group)
