@@ -1,9 +1,10 @@
 """Random commitments against the known answer [f(tau)]G (development aid; the answer needs no oracle: f(tau) by
 the library's evaluation kernel, then a one-coefficient commitment, compared as compressed encodings).
-usage: python scripts/fuzz_msm.py SECONDS [SEED]
+usage: python scripts/fuzz_msm.py SECONDS [SEED [MULTIPLE]]
 Sizes 1 .. 2^18 (log-uniform), window widths 0 (automatic) or 2 .. 20, scalars uniform or from a small set of
 special values (0, 1, r - 1, (r - 1) / 2, (r + 1) / 2, 2^254, repeated), single commitments, batches, and openings
-checked by the pairing equation."""
+checked by the pairing equation.  With MULTIPLE (e.g. 2048) the lengths are whole multiples of it where the SRS is
+long enough: together with PLONK_HIP_FRONT_END=scalars every such commitment takes the sort's first pass from the scalars."""
 import os
 import random
 import sys
@@ -17,6 +18,7 @@ from plonk_amd.prover import R_MOD, to_mont
 
 seconds = float(sys.argv[1])
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+multiple = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, (R_MOD + 1) // 2, 1 << 254, (1 << 254) - 1, (1 << 255) % R_MOD]
 t0 = last = time.perf_counter()
 cases = failures = 0
@@ -29,6 +31,8 @@ while time.perf_counter() - t0 < seconds:
     tau_g2 = plonk_amd.kzg_setup_tau_g2(tau)
     for _ in range(4):
         m = rnd.randint(1, n)
+        if m >= multiple:
+            m -= m % multiple
         kind = rnd.random()
         if kind < 0.5:
             f = np.frombuffer(rnd.randbytes(m * 32), dtype=np.uint64).reshape(m, 4).copy()
