@@ -157,17 +157,8 @@ int sort_selftest(plonk_hip_ctx *ctx);
 size_t sort_pairs_temp_bytes(size_t n, int end_bit);
 int sort_pairs_passes(int end_bit);
 // result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one.
-// first_counts_done: the per-tile bin counts of the first pass are in place already (written by the
-// producer of the keys: see sort_pairs_first_pass).
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-               int end_bit, void *temp, size_t temp_bytes, bool first_counts_done = false);
-// What a producer of the keys needs to leave the first pass's counts behind: a tile is `tile` consecutive
-// pairs, its counts are `bins` 32-bit words at counts + tile_index * bins, bin = key & mask.
-struct SortFirstPass {
-    uint32_t tile, bins, mask;
-    uint32_t *counts;
-};
-SortFirstPass sort_pairs_first_pass(int end_bit, void *temp);
+               int end_bit, void *temp, size_t temp_bytes);
 // The same sort with the first pass made from the scalars (the pairs of scalar i: window w -> key = |digit| - 1
 // or nbuckets for digit 0, val = w * srs_n + first + i with the sign in bit 31); temp as for
 // sort_pairs(n * nwin pairs); result where sort_pairs leaves it.

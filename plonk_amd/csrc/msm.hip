@@ -7,7 +7,8 @@
 //                                               of sign * table[w][i].
 // Pipeline (all on the context's stream, no host synchronisation):
 //   1. k_digits      scalars out of Montgomery form, nwin signed digits each -> (bucket, entry)
-//   2. sort_pairs    radix sort of the n*nwin pairs by bucket (sort.hip)
+//   2. sort_pairs    radix sort of the n*nwin pairs by bucket (sort.hip); large inputs: steps 1 and 2 as
+//                    sort_pairs_of_scalars, whose first pass takes its keys from the scalars themselves
 //   3. k_bounds      first sorted position of every bucket
 //   4. k_accumulate  one lane per fixed-length SEGMENT of the sorted list: gathers the affine
 //                    table points (one 128-byte line each) and adds them into an XYZZ
@@ -75,44 +76,6 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
         size_t at = (size_t)w * n + i;
         keys[at] = key;
         vals[at] = val;
-    }
-}
-
-// The same for whole tiles of the sort (n a multiple of the tile, at most kDigitsHistWindows windows): a block
-// takes `tile` consecutive scalars, and as the pairs are laid out window by window its digits of window w are
-// exactly sort tile w * (n / tile) + block.  It leaves that tile's bin counts for the sort's first pass behind
-// (bin = key & mask), which saves the sort one reading of all keys.
-static constexpr int kDigitsHistWindows = 16;
-__global__ __launch_bounds__(256) void k_digits_counts(const Fr *__restrict__ scalars, uint32_t n, uint32_t srs_n,
-                                                      uint32_t first, int c, int nwin, uint32_t nbuckets,
-                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                      uint32_t tile, uint32_t bins, uint32_t mask,
-                                                      uint32_t *__restrict__ counts) {
-    extern __shared__ uint32_t count[];  // [nwin][bins]
-    for (uint32_t j = threadIdx.x; j < (uint32_t)nwin * bins; j += blockDim.x) count[j] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * tile;
-    for (uint32_t r = threadIdx.x; r < tile; r += blockDim.x) {
-        const uint32_t i = base + r;
-        Fr k = fe_from_mont(scalars[i]);
-        const bool opposite = msm_folds_scalars(c) && scalar_fold(k);
-        uint32_t carry = 0;
-        for (int w = 0; w < nwin; w++) {
-            int32_t d = signed_digit(k, w, c, carry);
-            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            uint32_t key = mag == 0 ? nbuckets : mag - 1;
-            uint32_t val = ((uint32_t)w * srs_n + first + i) | (((d < 0) != opposite) ? 0x80000000u : 0u);
-            size_t at = (size_t)w * n + i;
-            keys[at] = key;
-            vals[at] = val;
-            atomicAdd(&count[(uint32_t)w * bins + (key & mask)], 1u);
-        }
-    }
-    __syncthreads();
-    const uint32_t tiles_per_window = n / tile;
-    for (uint32_t j = threadIdx.x; j < (uint32_t)nwin * bins; j += blockDim.x) {
-        const uint32_t w = j / bins, b = j % bins;
-        counts[((size_t)w * tiles_per_window + blockIdx.x) * bins + b] = count[j];
     }
 }
 
@@ -917,20 +880,10 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
         PLONK_TRY(sort_pairs_of_scalars(ctx, d_scalars, n, ctx->srs_n, first, pl.c, pl.nwin, nb, keys_a, keys_b, vals_a,
                                         vals_b, ctx->sort_tmp.ptr, tmp_bytes));
     } else {
-        const SortFirstPass fp = sort_pairs_first_pass(pl.c, ctx->sort_tmp.ptr);
-        // (a block per tile: worth it from about four blocks per CU on; at 2^20 the few long-running blocks cost
-        // 0.12 ms)
-        const bool with_counts = n % fp.tile == 0 && n / fp.tile >= 1024 && pl.nwin <= kDigitsHistWindows;
-        if (with_counts) {
-            hipLaunchKernelGGL(k_digits_counts, dim3((unsigned)(n / fp.tile)), dim3(256), (size_t)pl.nwin * fp.bins * 4, st,
-                               d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n, (uint32_t)first, pl.c, pl.nwin, nb, keys_a,
-                               vals_a, fp.tile, fp.bins, fp.mask, fp.counts);
-        } else {
-            hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
-                               (uint32_t)ctx->srs_n, (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
-        }
+        hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
+                           (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
         record(ctx, PH_SORT);
-        PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes, with_counts));
+        PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
     }
     if ((sort_pairs_passes(pl.c) & 1) == 0) {  // an even number of passes ends in the first pair of buffers
         keys_b = keys_a;

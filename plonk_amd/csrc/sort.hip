@@ -6,9 +6,9 @@
 //   k_radix_scan_*   exclusive prefix of those counts over (bin, tile) in bin-major order: where the
 //                    keys of bin b of tile t go (two levels: chunks of tiles, then the chunk totals)
 //   k_radix_scatter  one block per tile again: a stable rank for every key inside its tile (wave
-//                    level: the lanes holding the same digit are found with one ballot per key bit, a
-//                    counter per wave and bin in LDS carries the rank from round to round), the tile
-//                    reordered by bin in LDS, then written out in runs of consecutive addresses
+//                    level: a counter per wave and bin in LDS, advanced by one add-with-return per
+//                    key, or by ballots: see k_rank_selftest), the tile reordered by bin in LDS, then
+//                    written out in runs of consecutive addresses
 // The pairs cross HBM twice per pass (plus the keys once more for the counts); with 2^13 pairs per
 // tile and 2^8 bins a run is 128 bytes for uniformly distributed digits.  Skewed inputs (all keys
 // equal) only make the runs longer.
@@ -462,28 +462,18 @@ size_t sort_pairs_temp_bytes(size_t n, int end_bit) {
 
 // Sorts the pairs by the low end_bit key bits.  The passes alternate between the two buffer pairs, starting
 // from (keys_a, vals_a): the result is in (keys_b, vals_b) after an odd number of passes (sort_pairs_passes),
-// in (keys_a, vals_a) after an even one.
-// The first pass sorts by the lowest key bits (the key bits spread evenly over the passes, see sort_pairs).
-SortFirstPass sort_pairs_first_pass(int end_bit, void *temp) {
-    const int npasses = sort_pairs_passes(end_bit);
-    const int bits = npasses ? (end_bit + npasses - 1) / npasses : 0;
-    return SortFirstPass{(uint32_t)kTile, (uint32_t)kMaxBins, (1u << bits) - 1, (uint32_t *)temp};
-}
-
+// in (keys_a, vals_a) after an even one.  The key bits spread evenly over the passes.
 // Passes first_pass .. npasses - 1 over pairs of whole-tile lists; key bits [shift, end_bit) spread evenly.
 static void later_passes(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
-                         size_t n, int shift, int end_bit, int first_pass, int npasses, void *temp,
-                         bool first_counts_done) {
+                         size_t n, int shift, int end_bit, int first_pass, int npasses, void *temp) {
     const uint32_t ntiles = cdiv(n, kTile), nchunks = cdiv(ntiles, kChunkTiles);
     uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * kMaxBins;
     for (int p = first_pass; p < npasses; p++) {
         const int bits = (end_bit - shift + (npasses - p) - 1) / (npasses - p);
         const uint32_t *kin = (p & 1) ? keys_b : keys_a, *vin = (p & 1) ? vals_b : vals_a;
         uint32_t *kout = (p & 1) ? keys_a : keys_b, *vout = (p & 1) ? vals_a : vals_b;
-        if (p > first_pass || !first_counts_done) {
-            hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
-                               (1u << bits) - 1, hist);
-        }
+        hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
+                           (1u << bits) - 1, hist);
         hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(256), 0, ctx->stream, hist, ntiles, (uint32_t)kMaxBins,
                            chunk_total);
         hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, ctx->stream, chunk_total, nchunks,
@@ -496,11 +486,10 @@ static void later_passes(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b,
 }
 
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
-               int end_bit, void *temp, size_t temp_bytes, bool first_counts_done) {
+               int end_bit, void *temp, size_t temp_bytes) {
     if (n == 0) return PLONK_HIP_OK;
     if (n >= 0xffffffffull || temp_bytes < sort_pairs_temp_bytes(n, end_bit)) return PLONK_HIP_ERR_INVALID_ARG;
-    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, n, 0, end_bit, 0, sort_pairs_passes(end_bit), temp,
-                 first_counts_done);
+    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, n, 0, end_bit, 0, sort_pairs_passes(end_bit), temp);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
@@ -525,7 +514,7 @@ int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, siz
                        dim3(kDigitWaves * 64), 0, ctx->stream, d_scalars, (uint32_t)n,
                        (uint32_t)srs_n, (uint32_t)first, c, nwin, nbuckets, (uint32_t)bits, hist, chunk_total, chunk_tiles,
                        keys_b, vals_b);
-    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, total, bits, c, 1, npasses, temp, false);
+    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, total, bits, c, 1, npasses, temp);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
