@@ -700,6 +700,13 @@ def main():
             for _ in range(3):
                 be.kzg_commit(scalars)
             extras["g1_msm_2^%d_host_buffers_ms" % args.log_n] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            # the copy alone (pageable host memory to the resident buffer, synchronous), for the split of that figure
+            be.to_device(scalars, d_scalars)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                be.to_device(scalars, d_scalars)
+            be.sync()
+            extras["h2d_2^%d_scalars_ms" % args.log_n] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
             # the benchmark's own commitment four times in one call (tails run side by side)
             be.kzg_commit_many_dev([(d_scalars, n_local)] * 2)
             t0 = time.perf_counter()
