@@ -57,13 +57,15 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
     if (threadIdx.x < kMaxBins) hist[(size_t)blockIdx.x * kMaxBins + threadIdx.x] = count[threadIdx.x];
 }
 
-// The two scan levels work on counts laid out as [tile][bins] with bins = 64, 128 or 256.  A block is 256 lanes:
-// 256 / bins groups of `bins` lanes, lane b of a group owns bin b.
+// The two scan levels work on counts laid out as [tile][bins] with bins = 64, 128 or 256.  A block is kScanThreads lanes:
+// kScanThreads / bins groups of `bins` lanes, lane b of a group owns bin b (the more groups, the shorter the
+// chain of dependent loads each lane walks).
 //
 // Level 1: one block per chunk of chunk_tiles = kGroupTiles * groups tiles; group g scans the chunk's g-th run
 // of kGroupTiles tiles: hist[tile][b] becomes the number of keys of bin b in the earlier tiles of the chunk;
 // chunk_total[chunk][b] their number in the whole chunk.
-static constexpr uint32_t kGroupTiles = 128;
+static constexpr uint32_t kScanThreads = 1024, kGroupTiles = 32;
+static_assert(kChunkTiles == kGroupTiles * (kScanThreads / kMaxBins), "chunk of a pass with kMaxBins bins");
 
 // values[i * stride] for i in [first, last) become their exclusive running sum (starting from `run`); returns
 // the total.  Sixteen loads in flight at a time: the loop is bound by memory latency.
@@ -87,10 +89,10 @@ __device__ __forceinline__ void add_to_column(uint32_t *__restrict__ values, uin
     for (uint32_t i = first; i < last; i++) values[(size_t)i * stride] += add;
 }
 
-__global__ __launch_bounds__(256) void k_radix_scan_tiles(uint32_t *__restrict__ hist, uint32_t ntiles, uint32_t bins,
+__global__ __launch_bounds__(kScanThreads) void k_radix_scan_tiles(uint32_t *__restrict__ hist, uint32_t ntiles, uint32_t bins,
                                                          uint32_t *__restrict__ chunk_total) {
-    __shared__ uint32_t group_total[256];
-    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = 256 / bins;
+    __shared__ uint32_t group_total[kScanThreads];
+    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = kScanThreads / bins;
     uint32_t first = (blockIdx.x * groups + g) * kGroupTiles;
     if (first > ntiles) first = ntiles;
     const uint32_t last = first + kGroupTiles < ntiles ? first + kGroupTiles : ntiles;
@@ -114,11 +116,11 @@ __global__ __launch_bounds__(256) void k_radix_scan_tiles(uint32_t *__restrict__
 // Level 2: one block: chunk_total[chunk][b] becomes the position of the first key of bin b of that chunk in
 // the sorted order (all keys of smaller bins, then the earlier chunks' keys of bin b).  Group g takes the g-th
 // run of chunks.
-__global__ __launch_bounds__(256) void k_radix_scan_chunks(uint32_t *__restrict__ chunk_total, uint32_t nchunks,
+__global__ __launch_bounds__(kScanThreads) void k_radix_scan_chunks(uint32_t *__restrict__ chunk_total, uint32_t nchunks,
                                                           uint32_t bins) {
-    __shared__ uint32_t group_total[256];
+    __shared__ uint32_t group_total[kScanThreads];
     __shared__ uint32_t bin_total[kMaxBins];
-    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = 256 / bins;
+    const uint32_t t = threadIdx.x, b = t % bins, g = t / bins, groups = kScanThreads / bins;
     const uint32_t per_group = (nchunks + groups - 1) / groups;
     const uint32_t first = g * per_group < nchunks ? g * per_group : nchunks;
     const uint32_t last = first + per_group < nchunks ? first + per_group : nchunks;
@@ -132,12 +134,12 @@ __global__ __launch_bounds__(256) void k_radix_scan_chunks(uint32_t *__restrict_
         total += v;
     }
     // exclusive prefix of the bin totals (entries from `bins` on are zero; a logarithmic scan keeps it short)
-    bin_total[t] = t < bins ? total : 0u;
+    if (t < kMaxBins) bin_total[t] = t < bins ? total : 0u;
     __syncthreads();
     for (uint32_t off = 1; off < kMaxBins; off <<= 1) {
-        const uint32_t v = t >= off ? bin_total[t - off] : 0u;
+        const uint32_t v = t >= off && t < kMaxBins ? bin_total[t - off] : 0u;
         __syncthreads();
-        bin_total[t] += v;
+        if (t < kMaxBins) bin_total[t] += v;
         __syncthreads();
     }
     const uint32_t base = bin_total[b] - total + before;  // inclusive - own = exclusive
@@ -474,9 +476,9 @@ static void later_passes(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b,
         uint32_t *kout = (p & 1) ? keys_a : keys_b, *vout = (p & 1) ? vals_a : vals_b;
         hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, kin, n, (uint32_t)shift,
                            (1u << bits) - 1, hist);
-        hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(256), 0, ctx->stream, hist, ntiles, (uint32_t)kMaxBins,
+        hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, hist, ntiles, (uint32_t)kMaxBins,
                            chunk_total);
-        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, ctx->stream, chunk_total, nchunks,
+        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(kScanThreads), 0, ctx->stream, chunk_total, nchunks,
                            (uint32_t)kMaxBins);
         hipLaunchKernelGGL(ctx->lds_rank_in_lane_order ? k_radix_scatter<true> : k_radix_scatter<false>, dim3(ntiles),
                            dim3(kSortThreads), 0, ctx->stream, kin, vin, n, (uint32_t)shift, (uint32_t)bits, hist,
@@ -503,13 +505,13 @@ int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, siz
     if (!sort_pairs_of_scalars_applies(n, c, nwin) || temp_bytes < sort_pairs_temp_bytes(total, c))
         return PLONK_HIP_ERR_INVALID_ARG;
     const int bits = fused_first_bits(c), npasses = sort_pairs_passes(c);
-    const uint32_t bins = 1u << bits, groups = 256 / bins, chunk_tiles = kGroupTiles * groups;
+    const uint32_t bins = 1u << bits, groups = kScanThreads / bins, chunk_tiles = kGroupTiles * groups;
     const uint32_t blocks = (uint32_t)(n / kDigitTile), ntiles = blocks * (uint32_t)nwin, nchunks = cdiv(ntiles, chunk_tiles);
     uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * bins;
     hipLaunchKernelGGL(k_digits_hist, dim3(blocks), dim3(kDigitWaves * 64), (size_t)nwin * bins * 4, ctx->stream, d_scalars,
                        (uint32_t)n, c, nwin, nbuckets, bins, hist);
-    hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(256), 0, ctx->stream, hist, ntiles, bins, chunk_total);
-    hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, ctx->stream, chunk_total, nchunks, bins);
+    hipLaunchKernelGGL(k_radix_scan_tiles, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, hist, ntiles, bins, chunk_total);
+    hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(kScanThreads), 0, ctx->stream, chunk_total, nchunks, bins);
     hipLaunchKernelGGL(ctx->lds_rank_in_lane_order ? k_digits_scatter<true> : k_digits_scatter<false>, dim3(blocks),
                        dim3(kDigitWaves * 64), 0, ctx->stream, d_scalars, (uint32_t)n,
                        (uint32_t)srs_n, (uint32_t)first, c, nwin, nbuckets, (uint32_t)bits, hist, chunk_total, chunk_tiles,
