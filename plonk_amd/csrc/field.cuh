@@ -225,12 +225,32 @@ PLONK_HD Fe<C> fe_sqr(const Fe<C> &a) {
     return fe_mul(a, a);
 }
 
-// Montgomery form -> canonical integer limbs (multiply by 1).
+// Montgomery form -> canonical integer limbs: a / R mod p, i.e. the reduction half of a Montgomery product
+// alone (N rounds of "add the multiple of p that clears the lowest limb, drop that limb"; the running value
+// stays below 2^(32N) as both moduli leave the top bit of the top limb clear, and ends at most p).
 template <class C>
 PLONK_HD Fe<C> fe_from_mont(const Fe<C> &a) {
-    Fe<C> one = fe_zero<C>();
-    one.l[0] = 1;
-    return fe_mul(a, one);
+    constexpr int N = C::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = a.l[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t m = t[0] * C::INV;
+        uint64_t c = ((uint64_t)m * C::mod(0) + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            const uint64_t s = (uint64_t)m * C::mod(j) + t[j] + c;
+            t[j - 1] = (uint32_t)s;
+            c = s >> 32;
+        }
+        t[N - 1] = (uint32_t)c;
+    }
+    Fe<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    fe_reduce_once(r);
+    return r;
 }
 template <class C>
 PLONK_HD Fe<C> fe_to_mont(const Fe<C> &a) {
