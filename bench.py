@@ -86,6 +86,61 @@ def synthetic_scalars(n, seed):
     return sc
 
 
+FR_ONE = fr_limbs((1 << 256) % FR_MODULUS)  # 1 in Montgomery form
+
+
+def adversarial_scalar_sets(n, seed):
+    """Scalar sets that skew the bucket method (Montgomery residues, n x 4 limbs): every scalar equal
+    (each window's digits fall into ONE bucket), every scalar r - 1, one scalar in sixteen zero,
+    only the values 0 and 1, and all zero."""
+    rng = np.random.default_rng(seed)
+    one_value = synthetic_scalars(1, seed + 1)[0]
+    sparse = synthetic_scalars(n, seed + 2)
+    sparse[::16] = 0
+    bits = rng.integers(0, 2, size=n, dtype=np.uint64)
+    return {
+        "all_equal": np.tile(one_value, (n, 1)),
+        "all_r_minus_1": np.tile(FR_MINUS_ONE, (n, 1)),
+        "one_in_16_zero": sparse,
+        "zeros_and_ones": bits[:, None] * FR_ONE[None, :],
+        "all_zero": np.zeros((n, 4), dtype=np.uint64),
+    }
+
+
+def time_adversarial(be, log_n, tau, reps, uniform_ms=None, d_buf=None):
+    """One resident commitment per skewed scalar set on a context whose SRS (powers of tau) is loaded:
+    milliseconds by HIP events, the ratio to the uniform-scalar time, and the result against the known
+    answer [f(tau)]G (plonk/tests/kzg_tests.rs:36-69; f(tau) by the library's evaluation kernel, then a
+    one-coefficient commitment)."""
+    n = 1 << log_n
+    d_sc = d_buf if d_buf else be.malloc(n * 32)
+    d_out = be.malloc(144)
+    out = {}
+    if uniform_ms is None:
+        be.to_device(synthetic_scalars(n, 4242), d_sc)
+        be.kzg_commit_dev(d_sc, n, d_out)
+        be.sync()
+        uniform_ms = gpu_time(be, lambda: be.kzg_commit_dev(d_sc, n, d_out), reps)
+    out["uniform_ms"] = round(uniform_ms, 3)
+    worst = 0.0
+    for name, sc in adversarial_scalar_sets(n, 77 + log_n).items():
+        be.to_device(sc, d_sc)
+        be.kzg_commit_dev(d_sc, n, d_out)
+        be.sync()
+        got = be.from_device(d_out, (18,))
+        want = be.kzg_commit(np.ascontiguousarray(be.fr_eval(sc, tau)).reshape(1, 4))
+        enc = be.g1_compress(np.stack([np.asarray(want).reshape(18), got.reshape(18)]))
+        ms = gpu_time(be, lambda: be.kzg_commit_dev(d_sc, n, d_out), reps)
+        worst = max(worst, ms / uniform_ms)
+        out[name] = {"ms": round(ms, 3), "vs_uniform": round(ms / uniform_ms, 3),
+                     "equals_f_of_tau_times_G": bool(enc[0] == enc[1])}
+    out["worst_vs_uniform"] = round(worst, 3)
+    be.free(d_out)
+    if not d_buf:
+        be.free(d_sc)
+    return out
+
+
 def cpu_baseline(be, n_local, sample_log, threads, log_n_total):
     """The reference's commitment algorithm (one double-and-add per coefficient, then the sum;
     plonk/src/common/kzg.rs:53-58) restated in C (oracle/oracle.c), timed on a bounded sample."""

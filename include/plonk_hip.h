@@ -55,7 +55,11 @@ enum {
     PLONK_HIP_ERR_NOT_DIVISIBLE = -8, /* coset quotient asked for a polynomial Z_Omega does not divide */
     /* a compressed G1 encoding that `G1::deserialize_compressed` rejects; the reference panics on
      * `.expect("Failed to deserialize G1")` (plonk/src/setup_global_params/json.rs:30-33) */
-    PLONK_HIP_ERR_INVALID_POINT = -9
+    PLONK_HIP_ERR_INVALID_POINT = -9,
+    /* a kernel found its own intermediate data inconsistent (the bucket sort's output not in ascending
+     * order) and the results queued since the last successful wait must not be used; the context
+     * switches to its conservative sort and stays usable.  No counterpart in the reference. */
+    PLONK_HIP_ERR_INTERNAL = -10
 };
 
 /* ----------------------------------------------------------------------------------------

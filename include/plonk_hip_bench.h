@@ -38,6 +38,10 @@ int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *
  * when the context was created found the lanes of an instruction served in ascending order), 0 = the
  * ballot form that relies on nothing (the check failed, or PLONK_HIP_SORT_RANK=ballot was set). */
 int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx);
+/* Fault injection for the tests of the library's self-checks: with on != 0 the commitments of this context
+ * skip their bucket sort, so the accumulation meets keys that are not in ascending order, which it must report
+ * (PLONK_HIP_ERR_INTERNAL at the next wait) instead of returning a wrong point. */
+int plonk_hip_bench_skip_sort(plonk_hip_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -177,6 +177,11 @@ class Backend:
         "ballot" for the form that relies on nothing."""
         return "add" if self._lib.plonk_hip_bench_sort_rank_mode(self._ctx) else "ballot"
 
+    def debug_skip_sort(self, on):
+        """Fault injection for the tests: commitments skip their bucket sort (the accumulation must then report
+        keys out of order instead of returning a wrong point)."""
+        self._check(self._lib.plonk_hip_bench_skip_sort(self._ctx, 1 if on else 0))
+
     def bench_gather_rate(self, table_bytes):
         v = ctypes.c_double()
         self._check(self._lib.plonk_hip_bench_gather_rate(self._ctx, table_bytes, ctypes.byref(v)))

@@ -28,6 +28,25 @@ int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes) {
     return PLONK_HIP_OK;
 }
 
+int status_check(plonk_hip_ctx *ctx) {
+    if (!ctx->status_host) return PLONK_HIP_OK;
+    const uint32_t status = *(volatile uint32_t *)ctx->status_host;
+    if (!status) return PLONK_HIP_OK;
+    *(volatile uint32_t *)ctx->status_host = 0;
+    if (status & kStatusKeysOutOfOrder) {
+        // the one assumption the fast sort makes did not hold: from now on the form that makes none
+        ctx->lds_rank_in_lane_order = false;
+        ctx->last_error = "bucket sort left keys out of order; results since the last wait are invalid "
+                          "(the context now ranks keys by ballots)";
+    }
+    return PLONK_HIP_ERR_INTERNAL;
+}
+
+int stream_sync(plonk_hip_ctx *ctx) {
+    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return status_check(ctx);
+}
+
 void buf_release(DevBuf &b) {
     if (b.ptr) (void)hipFree(b.ptr);
     b.ptr = nullptr;
@@ -114,6 +133,12 @@ int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
             return PLONK_HIP_ERR_HIP;
         }
     }
+    if (hipHostMalloc((void **)&ctx->status_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&ctx->status_dev, ctx->status_host, 0) != hipSuccess) {
+        plonk_hip_ctx_destroy(ctx);
+        return PLONK_HIP_ERR_HIP;
+    }
+    *ctx->status_host = 0;
     if (resolve_static_scratch(device, &ctx->static_scratch) != hipSuccess) {
         plonk_hip_ctx_destroy(ctx);
         return PLONK_HIP_ERR_HIP;
@@ -132,7 +157,7 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->table,     &ctx->keys_a,    &ctx->keys_b,       &ctx->vals_a,    &ctx->vals_b,
-                      &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->red_a,
+                      &ctx->sort_tmp,  &ctx->bucket_start, &ctx->buckets,   &ctx->seg_part,  &ctx->big_list, &ctx->chunk_out, &ctx->red_a,
                       &ctx->red_b,     &ctx->red_lw,    &ctx->red_sum_a,    &ctx->red_sum_b, &ctx->scalars_stage,
                       &ctx->out_stage, &ctx->scratch_a, &ctx->scratch_b,    &ctx->scratch_c, &ctx->gen_table,      &ctx->level_a,   &ctx->level_b,
                       &ctx->stage_c,   &ctx->mul_ws,    &ctx->tree_ws,   &ctx->div_ws,       &ctx->interp_ws, &ctx->ntt_ws, &ctx->ntt3_ws};
@@ -154,9 +179,11 @@ void plonk_hip_ctx_destroy(plonk_hip_ctx *ctx) {
         buf_release(t.buckets);
         buf_release(t.seg_part);
         buf_release(t.big_list);
+        buf_release(t.chunk_out);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     delete ctx;
 }
 
@@ -173,6 +200,7 @@ const char *plonk_hip_strerror(int code) {
         case PLONK_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
         case PLONK_HIP_ERR_NOT_DIVISIBLE: return "polynomial is not divisible by the vanishing polynomial";
         case PLONK_HIP_ERR_INVALID_POINT: return "Failed to deserialize G1";
+        case PLONK_HIP_ERR_INTERNAL: return "inconsistent intermediate data on the GPU; see plonk_hip_last_error()";
         default: return "unknown error";
     }
 }
@@ -189,8 +217,7 @@ void *plonk_hip_ctx_stream(plonk_hip_ctx *ctx) { return ctx ? (void *)ctx->strea
 
 int plonk_hip_sync(plonk_hip_ctx *ctx) {
     PLONK_ENTER(ctx);
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 int plonk_hip_malloc(plonk_hip_ctx *ctx, size_t bytes, void **dptr) {
@@ -217,8 +244,7 @@ int plonk_hip_memcpy_h2d(plonk_hip_ctx *ctx, void *dst_dev, const void *src_host
 int plonk_hip_memcpy_d2h(plonk_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     PLONK_ENTER(ctx);
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 // ---------------------------------------------------------------------------- SRS
@@ -378,8 +404,7 @@ int plonk_hip_kzg_commit(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, u
     G1Jac *d_out = (G1Jac *)ctx->out_stage.ptr;
     PLONK_TRY(commit_host_sliced(ctx, coeffs, n, (Fr *)ctx->scalars_stage.ptr, d_out + 1, d_out));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs, const size_t *ns, size_t batch,
@@ -412,8 +437,7 @@ int plonk_hip_kzg_commit_batch(plonk_hip_ctx *ctx, const uint64_t *const *coeffs
     }
     PLONK_TRY(msm_join(ctx));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 // v_k = f(u_k) and the opening proofs for m points of one polynomial in device memory; the suffix scan
@@ -437,7 +461,7 @@ static int open_many_core(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const uin
         PLONK_TRY(msm_join(ctx));
         PLONK_HIP_TRY(ctx, hipMemcpyAsync(proofs + 18 * done, d_out, group * sizeof(G1Jac), hipMemcpyDeviceToHost,
                                           ctx->stream));
-        PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        PLONK_TRY(stream_sync(ctx));
     }
     return PLONK_HIP_OK;
 }
@@ -484,8 +508,7 @@ static int open_host_sliced(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n
     PLONK_TRY(msm_join(ctx));
     PLONK_TRY(g1_sum_dev(ctx, d_parts, slices, d_out));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(proof, d_out, sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 int plonk_hip_kzg_open_many(plonk_hip_ctx *ctx, const uint64_t *coeffs, size_t n, const uint64_t *us, size_t m,
@@ -533,6 +556,12 @@ int plonk_hip_bench_op_rate(plonk_hip_ctx *ctx, int op, double *ops_per_second) 
 }
 
 int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx) { return ctx && ctx->lds_rank_in_lane_order ? 1 : 0; }
+
+int plonk_hip_bench_skip_sort(plonk_hip_ctx *ctx, int on) {
+    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+    ctx->debug_skip_sort = on != 0;
+    return PLONK_HIP_OK;
+}
 
 int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *bytes_per_second) {
     PLONK_ENTER(ctx);
@@ -957,8 +986,7 @@ int plonk_hip_kzg_commit_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeff
         PLONK_TRY(msm_run_dev(ctx, (const Fr *)d_coeffs[b], ns[b], d_out + b, nullptr, batch > 1));
     PLONK_TRY(msm_join(ctx));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, batch * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 int plonk_hip_kzg_commit_open_many_dev(plonk_hip_ctx *ctx, const void *const *d_coeffs, const size_t *ns,
@@ -998,8 +1026,7 @@ int plonk_hip_kzg_commit_open_many_dev(plonk_hip_ctx *ctx, const void *const *d_
     }
     PLONK_TRY(msm_join(ctx));
     PLONK_HIP_TRY(ctx, hipMemcpyAsync(outs, d_out, m * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
-    PLONK_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PLONK_HIP_OK;
+    return stream_sync(ctx);
 }
 
 int plonk_hip_fr_scale_by_powers_dev(plonk_hip_ctx *ctx, void *d_coeffs, size_t n, const uint64_t w[4]) {

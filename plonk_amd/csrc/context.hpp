@@ -29,6 +29,9 @@ enum FrontEnd { kFrontEndAuto = 0, kFrontEndScalars, kFrontEndPairs };
 // from this many scalars on the first sort pass is made from the scalars (where its shape allows)
 static constexpr size_t kFrontEndScalarsMin = (size_t)1 << 21;
 
+// Bits of the context's status word (host memory the kernels can write; checked at every host wait).
+static constexpr uint32_t kStatusKeysOutOfOrder = 1u;
+
 enum MsmPhase { PH_DIGITS = 0, PH_SORT, PH_BOUNDS, PH_ACCUM, PH_FIXUP, PH_REDUCE, PH_COUNT };
 
 // One MSM whose tail is still to run (device pointers; bucket arrays are G1Xyzz28, see g1_28.cuh).
@@ -37,8 +40,9 @@ struct TailDesc {
     const uint32_t *start;      // bucket bounds
     const void *part;           // segment partials
     void *buckets;              // bucket sums (whole buckets already there)
-    const uint32_t *big_count;  // queue of the buckets that take a whole block
-    const uint32_t *big_list;
+    const uint32_t *queue;      // buckets whose partials take whole blocks, in chunks (msm.hip: k_classify)
+    void *chunk_out;            // chunk sums of the buckets of several chunks
+    uint32_t max_joins, max_items, chunk_parts;
     void *red;                  // row sums, column sums, bit sums of the reduction
     void *out;                  // G1Jac result, or null: stop after the bucket sums
     uint32_t seg_len, g_log, per_lane, group_blocks;
@@ -47,7 +51,7 @@ struct TailBatch {
     TailDesc d[kMaxTailSlots];
 };
 struct TailSlotBufs {
-    DevBuf bucket_start, buckets, seg_part, big_list;
+    DevBuf bucket_start, buckets, seg_part, big_list, chunk_out;
 };
 
 }  // namespace plonk
@@ -64,6 +68,7 @@ struct plonk_hip_ctx {
     // the sort ranks keys with one LDS add-with-return each (checked by sort_selftest when the context is created;
     // PLONK_HIP_SORT_RANK=ballot keeps the form that relies on nothing)
     bool lds_rank_in_lane_order = false;
+    bool debug_skip_sort = false;  // fault injection (plonk_hip_bench_skip_sort): hand the accumulation unsorted pairs
 
     // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form
     // (G1Affine28, 128 B each); level w, point i = [2^(c*w)] P_i at table[w * srs_n + i].
@@ -73,7 +78,7 @@ struct plonk_hip_ctx {
 
     // MSM workspace
     plonk::DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
-    plonk::DevBuf bucket_start, buckets, seg_part, big_list, red_a, red_b, red_lw, red_sum_a, red_sum_b;
+    plonk::DevBuf bucket_start, buckets, seg_part, big_list, chunk_out, red_a, red_b, red_lw, red_sum_a, red_sum_b;
     // A batch of MSMs (several commitments / openings queued by one call) defers the serial tails: every
     // MSM of the batch stops after its accumulation, leaving its bucket bounds, whole buckets and segment
     // partials in a slot of its own, and ONE set of tail launches (fix-up, row / column sums, bit sums,
@@ -103,6 +108,10 @@ struct plonk_hip_ctx {
     bool coset_ok[2][33] = {};
     bool ntt_lds_opt_in = false;  // large dynamic LDS enabled for the transform kernels on this device
 
+    // One word of mapped host memory that kernels set when they find their input inconsistent (kStatus* bits):
+    // no copy and no wait of its own, the host looks at it after the waits it performs anyway.
+    uint32_t *status_host = nullptr, *status_dev = nullptr;
+
     // this device's copy of the library's static scratch array (capi.hip), resolved at creation
     void *static_scratch = nullptr;
 
@@ -130,6 +139,12 @@ namespace plonk {
         int _rc = (expr);        \
         if (_rc != 0) return _rc; \
     } while (0)
+
+// hipStreamSynchronize on the context's stream, then the status word: PLONK_HIP_ERR_INTERNAL (and the word
+// cleared) if a kernel reported inconsistent input since the last look.
+int stream_sync(plonk_hip_ctx *ctx);
+// the look at the status word alone, for callers that have waited for the stream's work some other way
+int status_check(plonk_hip_ctx *ctx);
 
 // Grow `b` to at least `bytes` (contents are not preserved).
 int buf_reserve(plonk_hip_ctx *ctx, DevBuf &b, size_t bytes);

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
                                                        uint32_t seg_len, const G1Affine28 *__restrict__ table,
                                                        G1Xyzz28 *__restrict__ buckets,
-                                                       G1Xyzz28 *__restrict__ part) {
+                                                       G1Xyzz28 *__restrict__ part, uint32_t *status) {
     __shared__ uint4 line_buf[kBlock / 64][64 * 8];                           // 8 KiB per wave
     __shared__ uint32_t pair_buf[STAGED ? kBlock / 64 : 1][2][kStage][64];   // 8 KiB per wave
     const uint32_t lane = threadIdx.x & 63;
@@ -236,6 +236,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     uint32_t run_begin = begin;
     G1Xyzz28 acc = xyzz28_identity();
     bool staged_pending = false;
+    // The bucket bounds are only meaningful for keys in ascending order; a sort that lost it (see sort.hip on
+    // what its ranks rely on) is reported, not trusted: every change of key is checked, and the segment's first
+    // key against the one before it.
+    bool out_of_order = live && begin < end && ((begin > 0 && keys[begin - 1] > k) || k >= nbuckets);
     for (uint32_t it = 0; it < seg_len; it++) {  // the same trip count for every lane of the grid
         const uint32_t p = begin + it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this position's lines have landed
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         pair_at(it + 2, k2, v2);
         if (p < end) {
             if (k != cur) {
-                flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
+                out_of_order = out_of_order || k < cur || k >= nbuckets;
+                if (cur < nbuckets) flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
                 cur = k;
                 run_begin = p;
                 acc = xyzz28_identity();
@@ -275,7 +280,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         staged_pending = STAGED && ((it + 3) & (kStage - 1)) == 0 && it + 3 < seg_len;
         if (staged_pending) chunk_load(begin + it + 3);
     }
-    if (live) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
+    if (live && cur < nbuckets) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
+    if (out_of_order) __hip_atomic_store(status, kStatusKeysOutOfOrder, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,23 +510,59 @@ __device__ __forceinline__ G1Xyzz28 block_sum_coop(uint32_t cnt, CoopMem &m, At 
     return r;
 }
 
-// Buckets cut into more partials than a lane group handles go to the block path; the queue is
-// built before the accumulation (it depends only on the bucket bounds).
+// Buckets cut into more partials than a lane group handles go to the block path, in chunks of chunk_parts
+// partials (chosen by the host so that all chunks of the worst case run at once: the strided part of a block's
+// sum keeps every lane busy, its tree does not): one block sums a chunk, and a bucket of several chunks gets one
+// more sum over its chunk results (k_fixup_join).  A bucket that holds a whole window's digits (every scalar equal) is cut into tens of
+// thousands of partials: by chunks its sum is two short trees spread over the GPU instead of one block's long
+// chain.  The queue is built before the accumulation (it depends only on the bucket bounds).
+// Queue words: [0] work items, [1] joins, [2] chunk slots handed out, [3] unused; max_joins x {bucket, first
+// slot, chunks}; then the items {bucket, chunk, slot or kDirectSlot}.
+static constexpr uint32_t kDirectSlot = 0xffffffffu, kQueueHead = 4;
+
 __global__ __launch_bounds__(256) void k_classify(const uint32_t *__restrict__ start, uint32_t nbuckets,
-                                                 uint32_t seg_len, uint32_t group_cap,
-                                                 uint32_t *__restrict__ big_count, uint32_t *__restrict__ big_list) {
+                                                 uint32_t seg_len, uint32_t group_cap, uint32_t chunk_parts,
+                                                 uint32_t *__restrict__ queue,
+                                                 uint32_t max_joins, uint32_t max_items, uint32_t max_slots,
+                                                 uint32_t *status) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     uint32_t lo = start[b], hi = start[b + 1];
-    if (lo == hi) return;
+    if (lo >= hi) return;
     uint32_t cnt = (hi - 1) / seg_len - lo / seg_len + 1;
-    if (cnt > group_cap) big_list[atomicAdd(big_count, 1u)] = b;
+    if (cnt <= group_cap) return;
+    uint32_t *joins = queue + kQueueHead, *items = joins + 3 * (size_t)max_joins;
+    const uint32_t nch = (cnt + chunk_parts - 1) / chunk_parts;
+    const uint32_t item0 = atomicAdd(&queue[0], nch);
+    // the host sized the queue for any bounds of ascending keys; anything else is reported, not written
+    bool fits = item0 + nch <= max_items;
+    uint32_t slot0 = kDirectSlot;
+    if (fits && nch > 1) {
+        slot0 = atomicAdd(&queue[2], nch);
+        const uint32_t j = atomicAdd(&queue[1], 1u);
+        fits = slot0 + nch <= max_slots && j < max_joins;
+        if (fits) {
+            joins[3 * j] = b;
+            joins[3 * j + 1] = slot0;
+            joins[3 * j + 2] = nch;
+        }
+    }
+    if (!fits) {
+        __hip_atomic_store(status, kStatusKeysOutOfOrder, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (uint32_t i = 0; i < nch; i++) {
+        uint32_t *it = items + 3 * (size_t)(item0 + i);
+        it[0] = b;
+        it[1] = i;
+        it[2] = nch > 1 ? slot0 + i : kDirectSlot;
+    }
 }
 
 // Blocks [0, group_blocks): a group of 2^g_log lanes per bucket; each lane adds up to per_lane of
 // the bucket's partials (stride 2^g_log), then a shuffle tree joins the group.  Whole buckets
 // (written by k_accumulate in its lazy form) and empty ones pass through the same code.
-// Blocks behind them: one block per queued bucket (grid-stride over the queue).
+// Blocks behind them: one block per queued chunk of a long bucket (grid-stride over the queue's items).
 __global__ __launch_bounds__(kTreeBlock) void k_fixup(TailBatch tb, uint32_t nbuckets) {
     __shared__ G1Xyzz28 sh[kTreeBlock / 64];
     // one MSM of the batch per grid row; blocks past this MSM's lane groups all serve its queue
@@ -528,17 +570,21 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(TailBatch tb, uint32_t nbu
     const uint32_t *__restrict__ start = d.start;
     const G1Xyzz28 *__restrict__ part = (const G1Xyzz28 *)d.part;
     G1Xyzz28 *__restrict__ buckets = (G1Xyzz28 *)d.buckets;
-    const uint32_t *__restrict__ big_count = d.big_count, *__restrict__ big_list = d.big_list;
     const uint32_t seg_len = d.seg_len, g_log = d.g_log, per_lane = d.per_lane, group_blocks = d.group_blocks;
     if (blockIdx.x >= group_blocks) {
-        const uint32_t count = *big_count;
+        const uint32_t *__restrict__ queue = d.queue;
+        G1Xyzz28 *__restrict__ chunk_out = (G1Xyzz28 *)d.chunk_out;
+        const uint32_t count = queue[0] < d.max_items ? queue[0] : d.max_items;
+        const uint32_t *__restrict__ items = queue + kQueueHead + 3 * (size_t)d.max_joins;
         for (uint32_t i = blockIdx.x - group_blocks; i < count; i += gridDim.x - group_blocks) {
-            uint32_t b = big_list[i];
-            uint32_t lo = start[b], hi = start[b + 1];
-            uint32_t s0 = lo / seg_len, s1 = (hi - 1) / seg_len;
+            const uint32_t b = items[3 * (size_t)i], first = items[3 * (size_t)i + 1] * d.chunk_parts;
+            const uint32_t slot = items[3 * (size_t)i + 2];
+            const uint32_t lo = start[b], hi = start[b + 1];
+            const uint32_t s0 = lo / seg_len, cnt = (hi - 1) / seg_len - s0 + 1;
+            const uint32_t m = cnt - first < d.chunk_parts ? cnt - first : d.chunk_parts;
             G1Xyzz28 acc =
-                block_sum(s1 - s0 + 1, sh, [&](uint32_t j) { return partial_of(part, s0, j, lo, seg_len); });
-            if (threadIdx.x == 0) buckets[b] = acc;
+                block_sum(m, sh, [&](uint32_t j) { return partial_of(part, s0, first + j, lo, seg_len); });
+            if (threadIdx.x == 0) (slot == kDirectSlot ? buckets[b] : chunk_out[slot]) = acc;
         }
         return;
     }
@@ -577,6 +623,23 @@ __global__ __launch_bounds__(kTreeBlock) void k_fixup(TailBatch tb, uint32_t nbu
         acc = add_inline(acc, o);
     }
     if (valid && r == 0 && !queued && !whole) buckets[b] = acc;  // identity for an empty bucket
+}
+
+// The buckets of several chunks: one block each sums the chunk results (grid-stride over the queue's joins;
+// grid row = MSM of the batch).
+__global__ __launch_bounds__(kTreeBlock) void k_fixup_join(TailBatch tb) {
+    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    const TailDesc &d = tb.d[blockIdx.y];
+    const uint32_t *__restrict__ queue = d.queue;
+    const G1Xyzz28 *__restrict__ chunk_out = (const G1Xyzz28 *)d.chunk_out;
+    G1Xyzz28 *__restrict__ buckets = (G1Xyzz28 *)d.buckets;
+    const uint32_t count = queue[1] < d.max_joins ? queue[1] : d.max_joins;
+    const uint32_t *__restrict__ joins = queue + kQueueHead;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t b = joins[3 * (size_t)i], slot0 = joins[3 * (size_t)i + 1], nch = joins[3 * (size_t)i + 2];
+        G1Xyzz28 acc = block_sum(nch, sh, [&](uint32_t j) { return chunk_out + slot0 + j; });
+        if (threadIdx.x == 0) buckets[b] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -860,7 +923,6 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     PLONK_TRY(buf_reserve(ctx, b_start, ((size_t)nb + 2) * 4));
     if (!d_buckets_out) PLONK_TRY(buf_reserve(ctx, b_buckets, (size_t)nb * sizeof(G1Xyzz28)));
     PLONK_TRY(buf_reserve(ctx, b_part, nseg * 2 * sizeof(G1Xyzz28)));
-    PLONK_TRY(buf_reserve(ctx, b_big, ((size_t)nb + 1) * 4));
 
     uint32_t *keys_a = (uint32_t *)ctx->keys_a.ptr, *keys_b = (uint32_t *)ctx->keys_b.ptr;
     uint32_t *vals_a = (uint32_t *)ctx->vals_a.ptr, *vals_b = (uint32_t *)ctx->vals_b.ptr;
@@ -868,14 +930,19 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     G1Xyzz28 *buckets = d_buckets_out ? (G1Xyzz28 *)d_buckets_out : (G1Xyzz28 *)b_buckets.ptr;
     G1Xyzz28 *part = (G1Xyzz28 *)b_part.ptr;
     const G1Affine28 *table = (const G1Affine28 *)ctx->table.ptr;
-    uint32_t *big_count = (uint32_t *)b_big.ptr, *big_list = big_count + 1;
 
     record(ctx, PH_DIGITS);
     // Large inputs: the sort's first pass is made from the scalars themselves, the unsorted pairs never exist
     // (sort.hip).  Small ones: pairs first, then the sort -- fewer and shorter launches.
     const bool from_scalars = ctx->front_end != kFrontEndPairs && sort_pairs_of_scalars_applies(n, pl.c, pl.nwin) &&
                               (ctx->front_end == kFrontEndScalars || n >= kFrontEndScalarsMin);
-    if (from_scalars) {
+    if (ctx->debug_skip_sort) {
+        // fault injection: the pairs as the digits come, in the buffers the sort would have left them in
+        const bool odd = (sort_pairs_passes(pl.c) & 1) != 0;
+        hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
+                           (uint32_t)first, pl.c, pl.nwin, nb, odd ? keys_b : keys_a, odd ? vals_b : vals_a);
+        record(ctx, PH_SORT);
+    } else if (from_scalars) {
         record(ctx, PH_SORT);
         PLONK_TRY(sort_pairs_of_scalars(ctx, d_scalars, n, ctx->srs_n, first, pl.c, pl.nwin, nb, keys_a, keys_b, vals_a,
                                         vals_b, ctx->sort_tmp.ptr, tmp_bytes));
@@ -905,24 +972,41 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     const uint32_t per_lane = std::max<uint32_t>(((size_t)nb << g_log) > 65536 ? 16u : 3u,
                                                  (uint32_t)std::ceil(2.0 * typical / (1u << g_log)));
     const uint32_t group_blocks = cdiv((size_t)nb << g_log, kTreeBlock);
-    PLONK_HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
-    hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, per_lane << g_log,
-                       big_count, big_list);
+    // Queue of the long buckets: the (bucket, segment) incidences number at most nseg + nb, a queued bucket has
+    // more than `cap` of them, one of several chunks more than chunk_parts.  Chunks of at least 256 partials, and
+    // long enough that about 512 blocks (what the GPU runs at once) cover every segment.
+    const uint32_t cap = per_lane << g_log;
+    const size_t incidences = nseg + nb;
+    uint32_t chunk_parts = 256;
+    while (chunk_parts < 8192 && (size_t)chunk_parts * 512 < nseg) chunk_parts *= 2;
+    const uint32_t max_joins = (uint32_t)(incidences / chunk_parts + 1);
+    const uint32_t max_items = (uint32_t)(incidences / chunk_parts + incidences / cap + 2);
+    const uint32_t max_slots = 2 * max_joins;
+    DevBuf &b_chunk = slot ? ctx->tail_bufs[slot - 1].chunk_out : ctx->chunk_out;
+    PLONK_TRY(buf_reserve(ctx, b_big, (kQueueHead + 3 * ((size_t)max_joins + max_items)) * 4));
+    PLONK_TRY(buf_reserve(ctx, b_chunk, (size_t)max_slots * sizeof(G1Xyzz28)));
+    uint32_t *queue = (uint32_t *)b_big.ptr;
+    PLONK_HIP_TRY(ctx, hipMemsetAsync(queue, 0, kQueueHead * 4, st));
+    hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, cap, chunk_parts, queue, max_joins,
+                       max_items, max_slots, ctx->status_dev);
     record(ctx, PH_ACCUM);
     if (seg_len % kStage == 0) {
         hipLaunchKernelGGL(k_accumulate<true>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
-                           seg_len, table, buckets, part);
+                           seg_len, table, buckets, part, ctx->status_dev);
     } else {
         hipLaunchKernelGGL(k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start,
-                           nb, seg_len, table, buckets, part);
+                           nb, seg_len, table, buckets, part, ctx->status_dev);
     }
     PLONK_HIP_TRY(ctx, hipGetLastError());
     TailDesc &d = ctx->pending[slot];
     d.start = start;
     d.part = part;
     d.buckets = buckets;
-    d.big_count = big_count;
-    d.big_list = big_list;
+    d.queue = queue;
+    d.chunk_out = b_chunk.ptr;
+    d.max_joins = max_joins;
+    d.max_items = max_items;
+    d.chunk_parts = chunk_parts;
     d.red = nullptr;  // assigned when the tails run
     d.out = d_buckets_out ? nullptr : (void *)d_out;
     d.seg_len = seg_len;
@@ -952,9 +1036,11 @@ int msm_join(plonk_hip_ctx *ctx) {
         group_blocks = std::max(group_blocks, tb.d[i].group_blocks);
         any_out = any_out || tb.d[i].out;
     }
-    const uint32_t big_blocks = std::min<uint32_t>(nb, 1024u);
+    // blocks for the queue of long buckets: usually empty, at most a few thousand chunks
+    const uint32_t big_blocks = std::min<uint32_t>(nb, 2048u);
     record(ctx, PH_FIXUP);
     hipLaunchKernelGGL(k_fixup, dim3(group_blocks + big_blocks, count), dim3(kTreeBlock), 0, ctx->stream, tb, nb);
+    hipLaunchKernelGGL(k_fixup_join, dim3(std::min<uint32_t>(nb, 256u), count), dim3(kTreeBlock), 0, ctx->stream, tb);
     record(ctx, PH_REDUCE);
     if (any_out) PLONK_TRY(reduce_buckets(ctx, tb, count, sbits, sbits, 0));
     record(ctx, PH_COUNT);

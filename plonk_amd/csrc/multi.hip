@@ -11,6 +11,7 @@
 // each device scans its own slice first with a zero carry-in, the host chains the slice totals
 // (S_g = H_g + u^len_g * S_(g+1), a handful of field operations), and each device scans again with its
 // true carry-in placed behind its slice as one more coefficient.
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -29,6 +30,10 @@ struct plonk_hip_multi {
     std::vector<size_t> first, count;  // SRS range of each sub-context
     size_t srs_n = 0;
     G1Jac *gather = nullptr;  // on the first device: one slot per sub-context, then the total
+    // direct[g]: device g can write the first device's memory (peer access enabled, or the same device); otherwise
+    // its partial is staged through slot g of `host_stage` (pinned host memory)
+    std::vector<char> direct;
+    G1Jac *host_stage = nullptr;
     std::string last_error;
     std::mutex mu;
 };
@@ -48,7 +53,18 @@ struct Bound {
     }
 };
 
-// fn(g) for every sub-context on a thread of its own; the first error wins
+// After a failure on one device the others may still have copies from the caller's buffers and kernels in
+// flight: nothing returns to the caller before every stream has drained.
+void drain_all(plonk_hip_multi *m) {
+    for (plonk_hip_ctx *ctx : m->sub) {
+        std::lock_guard<std::recursive_mutex> guard(ctx->mu);
+        if (hipSetDevice(ctx->device) == hipSuccess) (void)hipStreamSynchronize(ctx->stream);
+        ctx->npending = 0;
+        (void)status_check(ctx);
+    }
+}
+
+// fn(g) for every sub-context on a thread of its own; the first error wins (after all streams have drained)
 template <class Fn>
 int for_each_device(plonk_hip_multi *m, Fn fn) {
     const size_t p = m->sub.size();
@@ -64,6 +80,7 @@ int for_each_device(plonk_hip_multi *m, Fn fn) {
     for (size_t g = 0; g < p; g++) {
         if (rc[g] != PLONK_HIP_OK) {
             m->last_error = "device " + std::to_string(m->sub[g]->device) + ": " + m->sub[g]->last_error;
+            drain_all(m);
             return rc[g];
         }
     }
@@ -84,8 +101,13 @@ void split_ranges(plonk_hip_multi *m, size_t n) {
 // Device g sends the result at d_partial to its slot on the first device and marks the event.
 int send_partial(plonk_hip_multi *m, size_t g, const G1Jac *d_partial) {
     plonk_hip_ctx *ctx = m->sub[g];
-    PLONK_HIP_TRY(ctx, hipMemcpyPeerAsync(m->gather + g, m->sub[0]->device, d_partial, ctx->device, sizeof(G1Jac),
-                                          ctx->stream));
+    if (m->direct[g]) {
+        PLONK_HIP_TRY(ctx, hipMemcpyPeerAsync(m->gather + g, m->sub[0]->device, d_partial, ctx->device, sizeof(G1Jac),
+                                              ctx->stream));
+    } else {
+        // no peer access: as far as pinned host memory; the first device fetches it once the event has fired
+        PLONK_HIP_TRY(ctx, hipMemcpyAsync(m->host_stage + g, d_partial, sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream));
+    }
     PLONK_HIP_TRY(ctx, hipEventRecord(m->done[g], ctx->stream));
     return PLONK_HIP_OK;
 }
@@ -99,14 +121,28 @@ int sum_partials(plonk_hip_multi *m, const std::vector<size_t> &active, uint64_t
     // compact the active slots behind the per-device slots, in device order
     G1Jac *packed = m->gather + p, *total = m->gather + 2 * p;
     for (size_t k = 0; k < active.size(); k++) {
-        PLONK_HIP_TRY(c0, hipStreamWaitEvent(c0->stream, m->done[active[k]], 0));
-        PLONK_HIP_TRY(c0, hipMemcpyAsync(packed + k, m->gather + active[k], sizeof(G1Jac), hipMemcpyDeviceToDevice,
-                                         c0->stream));
+        const size_t g = active[k];
+        PLONK_HIP_TRY(c0, hipStreamWaitEvent(c0->stream, m->done[g], 0));
+        if (m->direct[g]) {
+            PLONK_HIP_TRY(c0, hipMemcpyAsync(packed + k, m->gather + g, sizeof(G1Jac), hipMemcpyDeviceToDevice, c0->stream));
+        } else {
+            PLONK_HIP_TRY(c0, hipMemcpyAsync(packed + k, m->host_stage + g, sizeof(G1Jac), hipMemcpyHostToDevice, c0->stream));
+        }
     }
     PLONK_TRY(g1_sum_dev(c0, packed, active.size(), total));
     PLONK_HIP_TRY(c0, hipMemcpyAsync(out, total, sizeof(G1Jac), hipMemcpyDeviceToHost, c0->stream));
     PLONK_HIP_TRY(c0, hipStreamSynchronize(c0->stream));
-    return PLONK_HIP_OK;
+    // the first device's stream waited for every partial: all local sums are complete, look at what they reported
+    int rc = PLONK_HIP_OK;
+    for (size_t g : active) {
+        std::lock_guard<std::recursive_mutex> guard(m->sub[g]->mu);
+        const int r = status_check(m->sub[g]);
+        if (r != PLONK_HIP_OK && rc == PLONK_HIP_OK) {
+            rc = r;
+            m->last_error = "device " + std::to_string(m->sub[g]->device) + ": " + m->sub[g]->last_error;
+        }
+    }
+    return rc;
 }
 
 Fr load_fr(const uint64_t v[4]) {
@@ -148,8 +184,30 @@ int plonk_hip_multi_create(const int *devices, int n_devices, plonk_hip_multi **
     }
     if (rc == PLONK_HIP_OK) {
         if (hipSetDevice(devices[0]) != hipSuccess ||
-            hipMalloc((void **)&m->gather, (3 * (size_t)n_devices + 1) * sizeof(G1Jac)) != hipSuccess)
+            hipMalloc((void **)&m->gather, (3 * (size_t)n_devices + 1) * sizeof(G1Jac)) != hipSuccess ||
+            hipHostMalloc((void **)&m->host_stage, (size_t)n_devices * sizeof(G1Jac), hipHostMallocPortable) != hipSuccess)
             rc = PLONK_HIP_ERR_HIP;
+    }
+    // Peer access towards the first device, so that the 144-byte partials travel GPU to GPU (xGMI inside a node)
+    // instead of through a bounce buffer of the runtime; a device that cannot have it stages through pinned host
+    // memory.  PLONK_HIP_MULTI_STAGED=1 forces the staged path (for tests on fewer GPUs than sub-contexts).
+    if (rc == PLONK_HIP_OK) {
+        const char *force = std::getenv("PLONK_HIP_MULTI_STAGED");
+        const bool staged = force && force[0] == '1';
+        m->direct.assign((size_t)n_devices, 0);
+        for (int g = 0; g < n_devices; g++) {
+            if (staged) continue;
+            if (devices[g] == devices[0]) {
+                m->direct[(size_t)g] = 1;
+                continue;
+            }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[g], devices[0]) != hipSuccess || !can) continue;
+            if (hipSetDevice(devices[g]) != hipSuccess) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) m->direct[(size_t)g] = 1;
+            (void)hipGetLastError();  // "already enabled" is not an error to carry forward
+        }
     }
     if (rc != PLONK_HIP_OK) {
         plonk_hip_multi_destroy(m);
@@ -170,6 +228,7 @@ void plonk_hip_multi_destroy(plonk_hip_multi *m) {
         (void)hipSetDevice(m->sub[0]->device);
         (void)hipFree(m->gather);
     }
+    if (m->host_stage) (void)hipHostFree(m->host_stage);
     for (plonk_hip_ctx *ctx : m->sub) plonk_hip_ctx_destroy(ctx);
     delete m;
 }
@@ -201,10 +260,11 @@ int plonk_hip_multi_srs_range(plonk_hip_multi *m, int index, size_t *first, size
 int plonk_hip_multi_srs_load_projective(plonk_hip_multi *m, const uint64_t *pts, size_t n) {
     if (!m || !pts) return PLONK_HIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> guard(m->mu);
-    if (n < m->sub.size()) return PLONK_HIP_ERR_INVALID_ARG;  // every device holds at least one point
+    if (n == 0) return PLONK_HIP_ERR_INVALID_ARG;
     m->srs_n = 0;
     split_ranges(m, n);
     int rc = for_each_device(m, [&](size_t g) -> int {
+        if (m->count[g] == 0) return PLONK_HIP_OK;  // fewer points than devices: the last ones hold none
         Bound b(m->sub[g]);
         PLONK_TRY(b.device());
         PLONK_TRY(srs_load_projective(m->sub[g], pts + 18 * m->first[g], m->count[g]));
@@ -219,10 +279,10 @@ int plonk_hip_multi_kzg_setup(plonk_hip_multi *m, const uint64_t tau[4], size_t 
     if (!m || !tau) return PLONK_HIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> guard(m->mu);
     const size_t n = degree + 1;
-    if (n < m->sub.size()) return PLONK_HIP_ERR_INVALID_ARG;
     m->srs_n = 0;
     split_ranges(m, n);
     int rc = for_each_device(m, [&](size_t g) -> int {
+        if (m->count[g] == 0) return PLONK_HIP_OK;  // fewer points than devices: the last ones hold none
         Bound b(m->sub[g]);
         PLONK_TRY(b.device());
         PLONK_TRY(srs_setup(m->sub[g], tau, m->first[g], m->count[g], out_pts ? out_pts + 18 * m->first[g] : nullptr));

@@ -14,6 +14,7 @@
 // equal) only make the runs longer.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "context.hpp"
 #include "msm_core.cuh"
@@ -32,12 +33,51 @@ static constexpr int kMaxBins = 256, kChunkTiles = 128;
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Lanes of one instruction that hold the same digit hit the same LDS counter, and the LDS serves them one after
+// the other: with skewed keys (every scalar equal, most digits zero) a plain add per lane takes 64 turns per
+// instruction.  While the first pending lane's digit is shared by at least kCrowd pending lanes, those lanes are
+// served together -- one add of their number by the first of them, ranks by position among them -- and what is
+// left goes through the per-lane adds.  Evenly spread digits pay one failed test per key.
+// Returns (WANT_RANK) the counter's value before this lane's key, as if the valid lanes had added 1 each in
+// ascending lane order.
+static constexpr uint32_t kCrowd = 16;
+
+template <bool WANT_RANK>
+__device__ __forceinline__ uint32_t count_digit(uint32_t *counters, uint32_t d, bool valid, uint32_t lane) {
+    uint64_t todo = __ballot(valid);
+    uint32_t rank = 0;
+    while (todo) {  // wave-uniform
+        const int first = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+        const uint64_t same = __ballot(d == d0) & todo;
+        const uint32_t cnt = (uint32_t)__popcll(same);
+        if (cnt < kCrowd) break;
+        uint32_t prior = 0;
+        if ((int)lane == first) {
+            if (WANT_RANK) prior = atomicAdd(&counters[d0], cnt);
+            else atomicAdd(&counters[d0], cnt);
+        }
+        if (WANT_RANK) {
+            prior = (uint32_t)__builtin_amdgcn_readlane((int)prior, first);
+            if ((same >> lane) & 1)
+                rank = prior + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+        }
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1) {
+        if (WANT_RANK) rank = atomicAdd(&counters[d], 1u);
+        else atomicAdd(&counters[d], 1u);
+    }
+    return rank;
+}
+
 // hist[tile][bin] = number of keys of the tile whose digit (key >> shift) & mask is bin
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ keys, size_t n, uint32_t shift,
                                                             uint32_t mask, uint32_t *__restrict__ hist) {
     __shared__ uint32_t count[kMaxBins];
     if (threadIdx.x < kMaxBins) count[threadIdx.x] = 0;
     __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
     const size_t base = (size_t)blockIdx.x * kTile;
     if (base + kTile <= n) {
         // whole tile: 16-byte loads, four keys per lane and load
@@ -45,13 +85,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
 #pragma unroll
         for (int r = 0; r < kSortItems / 4; r++) {
             const uint4 k = src[r * kSortThreads + threadIdx.x];
-            atomicAdd(&count[(k.x >> shift) & mask], 1u);
-            atomicAdd(&count[(k.y >> shift) & mask], 1u);
-            atomicAdd(&count[(k.z >> shift) & mask], 1u);
-            atomicAdd(&count[(k.w >> shift) & mask], 1u);
+            count_digit<false>(count, (k.x >> shift) & mask, true, lane);
+            count_digit<false>(count, (k.y >> shift) & mask, true, lane);
+            count_digit<false>(count, (k.z >> shift) & mask, true, lane);
+            count_digit<false>(count, (k.w >> shift) & mask, true, lane);
         }
     } else {
-        for (size_t i = base + threadIdx.x; i < n; i += kSortThreads) atomicAdd(&count[(keys[i] >> shift) & mask], 1u);
+        // the same trip count for every lane of a wave (count_digit votes)
+        for (size_t i0 = base; i0 < n; i0 += kSortThreads) {
+            const size_t i = i0 + threadIdx.x;
+            const bool valid = i < n;
+            count_digit<false>(count, valid ? (keys[i] >> shift) & mask : 0u, valid, lane);
+        }
     }
     __syncthreads();
     if (threadIdx.x < kMaxBins) hist[(size_t)blockIdx.x * kMaxBins + threadIdx.x] = count[threadIdx.x];
@@ -192,7 +237,7 @@ __device__ __forceinline__ void tile_scatter(ScatterMem<WAVES, ITEMS> &m, const 
         if (ATOMIC_RANK) {
             // one LDS operation: the counter's value before this lane's increment (see k_rank_selftest for the
             // order of the lanes of one instruction that this relies on)
-            rank[r] = valid ? atomicAdd(&m.wave_count[w][d], 1u) : 0u;
+            rank[r] = count_digit<true>(m.wave_count[w], d, valid, lane);
         } else {
             const uint64_t same = same_digit_lanes(d, bits, valid);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
@@ -340,7 +385,7 @@ __global__ __launch_bounds__(kDigitWaves * 64) void k_digits_hist(const Fr *__re
         uint32_t carry = 0, key, val;
         for (int w = 0; w < nwin; w++) {
             next_digit_pair(k, opposite, carry, c, nbuckets, 0u, key, val);
-            atomicAdd(&count[(uint32_t)w * bins + (key & mask)], 1u);
+            count_digit<false>(count + (uint32_t)w * bins, key & mask, true, threadIdx.x & 63);
         }
     }
     __syncthreads();
@@ -422,6 +467,88 @@ __global__ __launch_bounds__(64) void k_rank_selftest(uint32_t *__restrict__ mis
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// The second half of the check runs the real thing: both production scatter kernels (pairs in, scalars in) on
+// whole four-wave tiles with keys that are partly spread and partly crowded, two passes each, and the host looks
+// at what came out: keys ascending and, among equal keys, entries in their original order -- which is all a
+// stable sort can produce, whatever ranking it uses.
+static int selftest_real_kernels(plonk_hip_ctx *ctx, bool *ok) {
+    *ok = false;
+    const size_t n = 2 * (size_t)kTile + 1234;           // pairs of the plain sort: two whole tiles and a ragged one
+    const size_t ns = 2 * (size_t)kDigitTile;            // scalars of the sort that starts from the scalars
+    const int c = 13, nwin = (255 + c - 1) / c;         // 20 windows of 13 bits: two passes (6 + 7 key bits)
+    const uint32_t nbuckets = 1u << (c - 1);
+    const size_t total = std::max(n, ns * (size_t)nwin), tmp_bytes = sort_pairs_temp_bytes(total, 16);
+    if (!sort_pairs_of_scalars_applies(ns, c, nwin)) return PLONK_HIP_ERR_INVALID_ARG;
+    std::vector<uint32_t> keys(n), vals(n), out_k(total), out_v(total);
+    std::vector<Fr> scalars(ns);
+    uint32_t h = 12345u;
+    auto next = [&h]() {
+        h ^= h << 13;
+        h ^= h >> 17;
+        h ^= h << 5;
+        return h;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t r = next();
+        // stretches of spread keys, of two alternating keys and of one key
+        keys[i] = (i / 700) % 3 == 0 ? (r & 0xffffu) : ((i / 700) % 3 == 1 ? 0x1234u + (r & 1u) * 0x0100u : 0x00ffu);
+        vals[i] = (uint32_t)i;
+    }
+    for (size_t i = 0; i < ns; i++) {
+        for (int j = 0; j < FrCfg::N; j++) scalars[i].l[j] = (i / 300) % 2 ? next() : 0x9e3779b9u * (uint32_t)(j + 1);
+        scalars[i].l[FrCfg::N - 1] &= 0x3fffffffu;  // below the modulus
+    }
+    uint32_t *d[4] = {};
+    void *d_tmp = nullptr;
+    Fr *d_sc = nullptr;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipMalloc((void **)&d[i], (total + 64) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sc, ns * sizeof(Fr));
+    int rc = PLONK_HIP_OK;
+    bool good = e == hipSuccess;
+    if (good) {
+        // plain sort, 16 key bits: two passes, result back in the first pair of buffers
+        e = hipMemcpyAsync(d[0], keys.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d[2], vals.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) rc = sort_pairs(ctx, d[0], d[1], d[2], d[3], n, 16, d_tmp, tmp_bytes);
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_k.data(), d[0], n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_v.data(), d[2], n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipStreamSynchronize(ctx->stream);
+        good = e == hipSuccess && rc == PLONK_HIP_OK;
+        for (size_t i = 0; good && i < n; i++) {
+            good = out_v[i] < n && keys[out_v[i]] == out_k[i] &&
+                   (i == 0 || out_k[i - 1] < out_k[i] || (out_k[i - 1] == out_k[i] && out_v[i - 1] < out_v[i]));
+        }
+    }
+    if (good) {
+        // from the scalars: entry = window * ns + index, so equal keys must come out with ascending entries
+        const size_t pairs = ns * (size_t)nwin;
+        e = hipMemcpyAsync(d_sc, scalars.data(), ns * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            rc = sort_pairs_of_scalars(ctx, d_sc, ns, ns, 0, c, nwin, nbuckets, d[0], d[1], d[2], d[3], d_tmp, tmp_bytes);
+        const int res = (sort_pairs_passes(c) & 1) ? 1 : 0;  // which pair of buffers holds the result
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_k.data(), d[res], pairs * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_v.data(), d[2 + res], pairs * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipStreamSynchronize(ctx->stream);
+        good = e == hipSuccess && rc == PLONK_HIP_OK;
+        for (size_t i = 0; good && i < pairs; i++) {
+            const uint32_t entry = out_v[i] & 0x7fffffffu;
+            good = out_k[i] <= nbuckets && entry < pairs &&
+                   (i == 0 || out_k[i - 1] < out_k[i] ||
+                    (out_k[i - 1] == out_k[i] && (out_v[i - 1] & 0x7fffffffu) < entry));
+        }
+    }
+    for (int i = 0; i < 4; i++)
+        if (d[i]) (void)hipFree(d[i]);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_sc) (void)hipFree(d_sc);
+    PLONK_HIP_TRY(ctx, e);
+    PLONK_TRY(rc);
+    *ok = good;
+    return PLONK_HIP_OK;
+}
+
 int sort_selftest(plonk_hip_ctx *ctx) {
     uint32_t *d_bad = nullptr, bad = 1;
     PLONK_HIP_TRY(ctx, hipMalloc(&d_bad, 4));
@@ -435,6 +562,11 @@ int sort_selftest(plonk_hip_ctx *ctx) {
     (void)hipFree(d_bad);
     PLONK_HIP_TRY(ctx, e);
     ctx->lds_rank_in_lane_order = bad == 0;
+    if (ctx->lds_rank_in_lane_order) {
+        bool ok = false;
+        PLONK_TRY(selftest_real_kernels(ctx, &ok));
+        ctx->lds_rank_in_lane_order = ok;
+    }
     return PLONK_HIP_OK;
 }
 

@@ -129,6 +129,56 @@ def test_commit_skewed_buckets_known_answer(backend, log_n):
         assert same_point(backend.kzg_commit(sc), c.g1_mul(g, c.fr_eval(sc, tau))), name
 
 
+def test_commit_2_20_points_on_skewed_scalar_sets(backend):
+    """The scalar sets that skew the bucket method, at the size of the headline metric: every scalar equal (each
+    window's 2^20 digits in ONE bucket, which the fix-up sums by chunks and a join), every scalar r - 1, one in
+    sixteen zero, only 0 and 1, all zero, two values in stretches: commit(f) == [f(tau)]G
+    (plonk/tests/kzg_tests.rs:36-69) with f(tau) from the oracle."""
+    import bench
+    n = 1 << 20
+    rnd = random.Random(2020)
+    g = c.g1_generator()
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    sets = dict(bench.adversarial_scalar_sets(n, 97))
+    two = np.tile(c.fr_to_mont([rnd.randrange(o.R)])[0], (n, 1))
+    two[(np.arange(n) // 5000) % 2 == 1] = c.fr_to_mont([rnd.randrange(o.R)])[0]
+    sets["two_values_in_stretches"] = two
+    for name, sc in sets.items():
+        got = backend.kzg_commit(np.ascontiguousarray(sc))
+        assert same_point(got, c.g1_mul(g, c.fr_eval(sc, tau))), name
+    # the same sets side by side in one batch (deferred tails: one fix-up, one join, one reduction for all)
+    names = list(sets)
+    both = backend.kzg_commit_batch([np.ascontiguousarray(sets[k]) for k in names])
+    for k, got in zip(names, both):
+        assert same_point(got, c.g1_mul(g, c.fr_eval(sets[k], tau))), k
+
+
+def test_sort_reports_keys_out_of_order(backend):
+    """The accumulation checks that the sorted keys it walks are ascending and reports through the context's
+    status word if not.  Nothing in the library produces such a list, so the check is exercised through the
+    test hook that hands the accumulation an unsorted one: the next wait returns PLONK_HIP_ERR_INTERNAL, the
+    context falls back to ballot ranks and keeps working."""
+    rnd = random.Random(11)
+    n = 4096
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    be = plonk_amd.Backend(device=0)
+    try:
+        be.kzg_setup(tau, n - 1, want_points=False)
+        sc = c.fr_to_mont(rand_fr(rnd, n))
+        want = c.g1_mul(c.g1_generator(), c.fr_eval(sc, tau))
+        assert same_point(be.kzg_commit(sc), want)
+        be.debug_skip_sort(True)
+        with pytest.raises(plonk_amd.PlonkHipError) as err:
+            be.kzg_commit(sc)
+        assert err.value.code == -10
+        be.debug_skip_sort(False)
+        assert be.sort_rank_mode() == "ballot"
+        assert same_point(be.kzg_commit(sc), want)
+    finally:
+        be.close()
+
+
 @pytest.mark.parametrize("window_bits", [4, 9, 13, 15, 16, 17])
 def test_cooperative_sums_meet_identity_equal_and_opposite_operands(backend, window_bits):
     """The tail sums of small bucket arrays run on four cooperating waves whose barrier loops depend on every

@@ -89,3 +89,34 @@ def test_srs_loaded_from_projective_points_is_split_by_range(backend):
         assert same_point(m.kzg_commit(f), backend.kzg_commit(f))
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_uneven_ranges_fewer_points_than_devices_and_staged_partials(backend, staged, monkeypatch):
+    """Three sub-contexts with ranges of different lengths, an SRS of fewer points than sub-contexts (the last
+    hold none), polynomials that end inside the first range (the other devices contribute nothing: zero
+    slices), and the same with the partials staged through pinned host memory (the path of a device without
+    peer access to the first one, forced by PLONK_HIP_MULTI_STAGED=1)."""
+    monkeypatch.setenv("PLONK_HIP_MULTI_STAGED", "1" if staged else "0")
+    rng = np.random.default_rng(17)
+    for n in (2, 3, 4, 11, 1000):
+        tau = rand(rng, 1)[0]
+        backend.kzg_setup(tau, n - 1, want_points=False)
+        m = plonk_amd.MultiBackend([0, 0, 0])
+        try:
+            m.kzg_setup(tau, n - 1, want_points=False)
+            spans = [m.srs_range(g) for g in range(3)]
+            assert sum(cnt for _, cnt in spans) == n and [f for f, _ in spans] == sorted(f for f, _ in spans)
+            for length in sorted({n, max(2, n - 1), 2, max(2, spans[0][1]), max(2, spans[0][1] + 1)}):
+                if length > n:
+                    continue
+                f = rand(rng, length)
+                assert same_point(m.kzg_commit(f), backend.kzg_commit(f)), (n, length)
+                u = rand(rng, 1)[0]
+                v, proof = m.kzg_evaluate(f, u)
+                want_v, want_proof = backend.kzg_evaluate(f, u)
+                assert np.array_equal(v, want_v) and same_point(proof, want_proof), (n, length)
+            one = rand(rng, 1)
+            assert same_point(m.kzg_commit(one), backend.kzg_commit(one))
+        finally:
+            m.close()
