@@ -840,7 +840,7 @@ static int reduce_buckets(plonk_hip_ctx *ctx, const TailBatch &tb, uint32_t coun
     const uint32_t sums = H + L;
     const size_t all_sums = (size_t)sums * count;
     const uint32_t width = all_sums >= 1024 ? 64u : 128u;
-    if (all_sums < 512) {
+    if (all_sums <= 512) {  // (at 512 sums: 0.60 against 0.62 ms for the whole reduction of 2^16 buckets)
         hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums, count), dim3(256), 0, st, tb, H, L);
     } else {
         hipLaunchKernelGGL(k_row_col_sums, dim3(sums, count), dim3(width), 0, st, tb, H, L);
