@@ -343,9 +343,8 @@ class GlobalParameters:
 
 
 def kzg_setup_with_tau(degree, tau):
-    """common/kzg.rs:24-45 with tau supplied by the caller (the reference draws it from
-    ark_std::test_rng(); the draw itself is not restated -- its effect is fully captured by
-    plonk/data/srs.json).  Sequential accumulator = accumulator * tau."""
+    """common/kzg.rs:24-45 from line 29 on, with tau supplied by the caller (the reference's own draw,
+    tau = Fr::rand(test_rng()), is oracle/arkrng.py: kzg_setup).  Sequential accumulator = accumulator * tau."""
     acc = G1_GENERATOR
     out = [acc]
     for _ in range(1, degree + 1):
@@ -473,15 +472,20 @@ def prove_zero_test(gp, f, q, r):
     return dict(com_q=com_q, f_r=f_r, proof_f_r=proof_f_r, q_r=q_r, proof_q_r=proof_q_r)
 
 
-def _extra_points_count(f, k):
-    # f.degree() + 1 - k random extra interpolation points (protocols.rs:251-253); the
-    # reference draws them from ark_std::test_rng(), which is not restated.
+def _extra_points(f, k):
+    """The f.degree() + 1 - k extra interpolation points of the running-product / running-sum polynomial t
+    (protocols.rs:251-253, 354-356, 469-471, 589-591): drawn from a FRESH ark_std::test_rng(), all the values
+    first, then all the abscissae.  Returns (xs, ys)."""
     extra = poly_degree(f) + 1 - k
     if extra < 0:
         raise OverflowError("usize underflow panic in the reference")
-    if extra > 0:
-        raise NotImplementedError("extra random interpolation points need ark_std::test_rng()")
-    return extra
+    if extra == 0:
+        return [], []
+    from . import arkrng
+    rng = arkrng.test_rng()
+    ys = [arkrng.fr_rand(rng) for _ in range(extra)]
+    xs = [arkrng.fr_rand(rng) for _ in range(extra)]
+    return xs, ys
 
 
 def _shift(f, w):
@@ -496,8 +500,8 @@ def compute_t_and_t1_product_check(Omega, f):
     for e in evals:
         acc = acc * e % R
         t_y.append(acc)
-    _extra_points_count(f, k)
-    t = interpolate_polynomial(Omega, t_y)
+    xs, ys = _extra_points(f, k)
+    t = interpolate_polynomial(list(Omega) + xs, t_y + ys)
     t1 = poly_sub(_shift(t, Omega[1]), poly_mul(t, _shift(f, Omega[1])))
     return t, t1
 
@@ -509,8 +513,8 @@ def compute_t_and_t1_product_check_rational_functions(Omega, f, g):
     for x in Omega:
         acc = acc * poly_eval(f, x) % R * fr_inv(poly_eval(g, x)) % R
         t_y.append(acc)
-    _extra_points_count(f, k)
-    t = interpolate_polynomial(Omega, t_y)
+    xs, ys = _extra_points(f, k)
+    t = interpolate_polynomial(list(Omega) + xs, t_y + ys)
     w = Omega[1]
     t1 = poly_sub(poly_mul(_shift(t, w), _shift(g, w)), poly_mul(t, _shift(f, w)))
     return t, t1
@@ -523,8 +527,8 @@ def compute_t_and_t1_sum_check(Omega, f):
     for x in Omega:
         acc = (acc + poly_eval(f, x)) % R
         t_y.append(acc)
-    _extra_points_count(f, k)
-    t = interpolate_polynomial(Omega, t_y)
+    xs, ys = _extra_points(f, k)
+    t = interpolate_polynomial(list(Omega) + xs, t_y + ys)
     w = Omega[1]
     t1 = poly_sub(_shift(t, w), poly_add(t, _shift(f, w)))
     return t, t1
@@ -539,8 +543,8 @@ def compute_t_and_t1_prescribed_permutation_check(Omega, f, g, W, r, s):
         den = (r - s * x - poly_eval(g, x)) % R
         acc = acc * num % R * fr_inv(den) % R
         t_y.append(acc)
-    _extra_points_count(f, k)
-    t = interpolate_polynomial(Omega, t_y)
+    xs, ys = _extra_points(f, k)
+    t = interpolate_polynomial(list(Omega) + xs, t_y + ys)
     w = Omega[1]
     t_w_x = _shift(t, w)
     r_s_w_x = poly_trim([r, (-s * w) % R])
@@ -620,6 +624,72 @@ def prove_T_S_zero_test(gp, w, q, T, S, r):
     return dict(com_q=com_q, T_r=T_r, proof_T_r=proof_T_r, T_w_r=T_w_r, proof_T_w_r=proof_T_w_r,
                 T_w2_r=T_w2_r, proof_T_w2_r=proof_T_w2_r, S_r=S_r, proof_S_r=proof_S_r,
                 q_r=q_r, proof_q_r=proof_q_r)
+
+
+# ---------------------------------------------------------------------------
+# common/protocols.rs (verifier halves).  kzg_verify(com, u, v, proof) -> bool is passed in: the pairing check of
+# oracle/pairing.py, or, for a test SRS whose trapdoor is known, the same equation checked in G1.
+# ---------------------------------------------------------------------------
+def kzg_verify_with_tau(tau):
+    """com - [v]G == [tau - u] proof: what e(com - vG, H) == e(proof, tau H - u H) (kzg.rs:91-98) states, for
+    a known trapdoor."""
+    def check(com, u, v, proof):
+        return g1_eq(g1_sub(com, g1_mul(G1_GENERATOR, v)), g1_mul(proof, (tau - u) % R))
+    return check
+
+
+def verify_equality(kzg_verify, com_f, com_g, r, p):
+    """common/protocols.rs:144-154."""
+    return (p["y_f"] == p["y_g"] and kzg_verify(com_f, r, p["y_f"], p["proof_f"])
+            and kzg_verify(com_g, r, p["y_g"], p["proof_g"]))
+
+
+def verify_zero_test(kzg_verify, k, com_f, r, p):
+    """common/protocols.rs:207-217."""
+    return (p["f_r"] == p["q_r"] * (pow(r, k, R) - 1) % R
+            and kzg_verify(p["com_q"], r, p["q_r"], p["proof_q_r"])
+            and kzg_verify(com_f, r, p["f_r"], p["proof_f_r"]))
+
+
+def verify_zero_on_roots_test(kzg_verify, roots, com_f, r, p):
+    """common/protocols.rs:220-232."""
+    z_r = poly_eval(construct_vanishing_polynomial_from_roots(roots), r)
+    return (p["f_r"] == p["q_r"] * z_r % R
+            and kzg_verify(p["com_q"], r, p["q_r"], p["proof_q_r"])
+            and kzg_verify(com_f, r, p["f_r"], p["proof_f_r"]))
+
+
+def _verify_t_q_common(kzg_verify, w, k, r, p, last, identity):
+    return (p["t_w_k_minus_1"] == last and identity
+            and kzg_verify(p["com_t"], pow(w, k - 1, R), p["t_w_k_minus_1"], p["proof_t_w_k_minus_1"])
+            and kzg_verify(p["com_t"], r, p["t_r"], p["proof_t_r"])
+            and kzg_verify(p["com_t"], r * w % R, p["t_w_r"], p["proof_t_w_r"])
+            and kzg_verify(p["com_q"], r, p["q_r"], p["proof_q_r"]))
+
+
+def verify_product_check(kzg_verify, w, k, com_f, r, p):
+    """common/protocols.rs:312-333."""
+    z = (pow(r, k, R) - 1) % R
+    ok = (p["t_w_r"] - p["t_r"] * p["f_w_r"]) % R == p["q_r"] * z % R
+    return (_verify_t_q_common(kzg_verify, w, k, r, p, 1, ok)
+            and kzg_verify(com_f, r * w % R, p["f_w_r"], p["proof_f_w_r"]))
+
+
+def verify_product_check_rational_functions(kzg_verify, w, k, com_f, com_g, r, p):
+    """common/protocols.rs:426-450."""
+    z = (pow(r, k, R) - 1) % R
+    ok = (p["t_w_r"] * p["g_w_r"] - p["t_r"] * p["f_w_r"]) % R == p["q_r"] * z % R
+    return (_verify_t_q_common(kzg_verify, w, k, r, p, 1, ok)
+            and kzg_verify(com_f, r * w % R, p["f_w_r"], p["proof_f_w_r"])
+            and kzg_verify(com_g, r * w % R, p["g_w_r"], p["proof_g_w_r"]))
+
+
+def verify_sum_check(kzg_verify, w, k, com_f, r, p):
+    """common/protocols.rs:535-556."""
+    z = (pow(r, k, R) - 1) % R
+    ok = (p["t_w_r"] - (p["t_r"] + p["f_w_r"])) % R == p["q_r"] * z % R
+    return (_verify_t_q_common(kzg_verify, w, k, r, p, 0, ok)
+            and kzg_verify(com_f, r * w % R, p["f_w_r"], p["proof_f_w_r"]))
 
 
 # ---------------------------------------------------------------------------

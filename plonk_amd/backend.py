@@ -264,6 +264,14 @@ class Backend:
         self._check(self._lib.plonk_hip_kzg_setup(self._ctx, _u64(tau), degree, _u64(out) if want_points else None))
         return out
 
+    def kzg_setup_own_tau(self, degree, want_points=True):
+        """`kzg_setup(degree)` with the reference's own trapdoor, tau = Fr::rand(&mut ark_std::test_rng())
+        (kzg.rs:25-28): returns (tau_powers_g1 or None, tau_g2 as its 96-byte compressed encoding).  With
+        degree = 21 this is plonk/data/srs.json."""
+        from .ark_rng import TestRng
+        tau = TestRng().fr()
+        return self.kzg_setup(tau, degree, want_points), kzg_setup_tau_g2(tau)
+
     def kzg_setup_range(self, tau, first, count, want_points=False):
         """SRS slice [tau^first .. tau^(first+count-1)]G for point-range sharding."""
         tau = _fr(tau).reshape(4)
