@@ -59,7 +59,7 @@ def measured_traffic(kernel, workload_key):
         with open(TRAFFIC_FILE) as fh:
             rec = json.load(fh)
         entry = rec["entries"][workload_key][kernel]
-        return int(entry["bytes"]), "rocprofv3 counter passes (2 x FETCH_SIZE + WRITE_SIZE) of build %s: %s" % (
+        return int(entry["bytes"]), "rocprofv3 counter passes (size-resolved TCC_EA0_RDREQ_{128,64,32}B + WRITE_SIZE) of build %s: %s" % (
             rec.get("commit", "?"), entry.get("what", ""))
     except (OSError, KeyError, ValueError):
         return None, "no counter record for this workload in profiles/traffic.json (scripts/profile.sh writes it)"
@@ -157,6 +157,7 @@ def cpu_baseline(be, n_local, sample_log, threads, log_n_total):
         "value": m / dt / 1e6,
         "unit": "Mpts/s",
         "cores": threads,
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": "2^%d points of the same SRS, naive per-coefficient double-and-add + sum "
                   "(the reference's kzg_commit loop), %.2f s" % (sample_log, dt),
@@ -346,11 +347,14 @@ def time_small_msm(log_n, reps, mad_peak):
     be.kzg_commit_dev(d_sc, n, d_out)
     phases = be.msm_phase_ms()
     plan = be.msm_plan()
+    be.profile(False)
+    adversarial = time_adversarial(be, log_n, np.array([3, 1, 4, 1], dtype=np.uint64), reps, uniform_ms=ms, d_buf=d_sc)
     be.free(d_sc)
     be.free(d_out)
     be.close()
     work = MADS_PER_POINT * n
     return {
+        "adversarial_2^%d" % log_n: adversarial,
         "g1_msm_2^%d_ms" % log_n: round(ms, 3),
         "g1_msm_2^%d_mpts_per_s" % log_n: round(n / ms / 1e3, 1),
         "g1_msm_2^%d_in_a_batch_of_8_ms" % log_n: round(batch_ms, 3),
@@ -768,6 +772,14 @@ def main():
             be.kzg_commit_many_dev([(d_scalars, n_local)] * 4)
             extras["g1_msm_2^%d_in_a_batch_of_4_ms" % args.log_n] = round((time.perf_counter() - t0) / 4 * 1e3, 3)
             extras.update(time_small_msm(20, 10, peak))
+            # scalar sets that skew the bucket method, at both sizes of the headline metric, each against [f(tau)]G
+            extras["adversarial"] = {
+                "2^20": extras.pop("adversarial_2^20"),
+                "2^%d" % args.log_n: time_adversarial(be, args.log_n, tau, 3, uniform_ms=ms_per_step, d_buf=d_scalars),
+                "note": "one resident commitment per set (every scalar equal, every scalar r - 1, one in sixteen zero, "
+                        "only 0 and 1, all zero), ms by HIP events; vs_uniform: against uniform scalars of the same size "
+                        "on the same context"}
+            be.to_device(scalars, d_scalars)
             extras.update(transform_rooflines(be, 20, 16, 5, peak))
             extras["fr_ntt_2^20_ms"] = round(extras["ntt_roofline"]["ms"] / 16, 4)
             if not args.no_cpu_baseline:

@@ -173,8 +173,10 @@ int plonk_hip_kzg_setup_tau_g2(const uint64_t tau[4], uint8_t out[96]);
  * only G1 arithmetic depends on the arguments; the Miller-loop lines of H and tau H are computed once per
  * tau_g2 and kept.  tau_g2 = gp.tau_g2 (kzg.rs:20) in the 96-byte compressed form of plonk/data/srs.json; it is
  * validated (encoding, curve, subgroup) when first seen: PLONK_HIP_ERR_INVALID_POINT otherwise.  com and proof
- * are Jacobian points as everywhere in this interface and are taken as valid group elements (the reference's
- * types guarantee it); u, v Montgomery limbs. */
+ * are Jacobian points as everywhere in this interface; each must lie on the curve (checked:
+ * PLONK_HIP_ERR_INVALID_POINT otherwise) and in the prime-order subgroup (PRECONDITION, not checked: the
+ * reference's G1 type guarantees both through validated deserialisation; points made by this library or decoded
+ * by plonk_hip_g1_decompress with check_subgroup != 0 satisfy it); u, v Montgomery limbs. */
 int plonk_hip_kzg_verify(const uint8_t tau_g2[96], const uint64_t com[18], const uint64_t u[4], const uint64_t v[4],
                          const uint64_t proof[18], int *ok);
 /* The n kzg_verify calls of one proof (15 in the reference's verifier: protocols.rs:229-231, 706-718, 804-808,
@@ -356,7 +358,10 @@ int plonk_hip_fr_ratio_prefix_product_dev(plonk_hip_ctx *ctx, void *d_num, void 
  * bytes, held by every GPU the library runs on until the process ends), and a zero denominator is reported
  * through *d_zero_flag (a device int the caller owns: 0 = fine, 1 = some d_den[i] was zero and d_num is
  * unspecified) instead of an error code.  n <= 2^24, else PLONK_HIP_ERR_INVALID_ARG.  All contexts on one
- * GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race. */
+ * GPU share that GPU's array; the library orders their uses of it with one event per GPU (waited for ahead of the
+ * scan, recorded behind it), so calls on different contexts of one GPU do not race -- they serialise.  (Under
+ * stream capture that wait would pull the other context's stream into the capture: capture with one context per
+ * GPU.)  Work the caller queues on streams of its own is not covered. */
 int plonk_hip_fr_ratio_prefix_product_dev_noalloc(plonk_hip_ctx *ctx, void *d_num, void *d_den, size_t n,
                                                   int *d_zero_flag);
 

@@ -64,6 +64,10 @@ static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 static std::mutex g_static_mu;
 static void *g_static_ptr[256];  // per device ordinal
+// Every context on a GPU shares that GPU's array, each with a stream of its own: an event per GPU, recorded behind
+// each use and waited for ahead of the next, puts the uses in one order (no allocation per call: the event is made
+// when the first context on the GPU is created).
+static hipEvent_t g_static_done[256];
 
 // The device must be current on the calling thread.
 static hipError_t resolve_static_scratch(int device, void **out) {
@@ -74,6 +78,8 @@ static hipError_t resolve_static_scratch(int device, void **out) {
         hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!ptr) return hipErrorInvalidSymbol;
+        e = hipEventCreateWithFlags(&g_static_done[device], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
         g_static_ptr[device] = ptr;
     }
     *out = g_static_ptr[device];
@@ -1132,7 +1138,17 @@ int plonk_hip_fr_ratio_prefix_product_dev_noalloc(plonk_hip_ctx *ctx, void *d_nu
     if (n == 0) return PLONK_HIP_OK;
     PLONK_TRY(batch_inverse(ctx, (Fr *)d_den, n, d_zero_flag));
     PLONK_TRY(pointwise_mul(ctx, (const Fr *)d_num, (const Fr *)d_den, (Fr *)d_num, n));
-    PLONK_TRY(prefix_scan(ctx, (Fr *)d_num, n, true, (Fr *)ctx->static_scratch));
+    {
+        // the scan is the part that uses the GPU's shared array: behind the last use by any context, ahead of the next
+        std::lock_guard<std::mutex> guard(g_static_mu);
+        hipEvent_t done = g_static_done[ctx->device];
+        PLONK_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, done, 0));
+        int rc = prefix_scan(ctx, (Fr *)d_num, n, true, (Fr *)ctx->static_scratch);
+        // recorded even after a failed launch: whatever part of the scan was queued still uses the array
+        hipError_t e = hipEventRecord(done, ctx->stream);
+        PLONK_TRY(rc);
+        PLONK_HIP_TRY(ctx, e);
+    }
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }

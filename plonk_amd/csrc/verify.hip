@@ -624,6 +624,13 @@ static P1 joint_scalar_mul(const std::vector<Term> &terms) {
     }
     return acc;
 }
+// y^2 == x^3 + 4: what `G1::deserialize_compressed` guarantees for every point the reference's kzg_verify sees.
+// (Membership in the prime-order subgroup is the caller's precondition: points produced by this library or decoded
+// with the subgroup check are in it.)
+static bool a1_on_curve(const A1 &p) {
+    const Fp two = fe_dbl(fq_one()), four = fe_dbl(two);
+    return fe_eq(fe_sqr(p.y), fe_add(fe_mul(fe_sqr(p.x), p.x), four));
+}
 static Term make_term(const G1Jac &p, const Fr &k_mont) {
     Term t;
     t.skip = !jac_to_affine(p, t.p);
@@ -659,6 +666,9 @@ static int verify_folded(const uint8_t tau_g2[96], size_t n, const uint64_t *com
         const Fr u = load_fr(us + 4 * i), v = load_fr(vs + 4 * i);
         left.push_back(make_term(com, w));
         left.push_back(make_term(proof, fe_mul(w, u)));
+        // a pairing of points off the curve means nothing, whatever it evaluates to
+        for (size_t k = left.size() - 2; k < left.size(); k++)
+            if (!left[k].skip && !a1_on_curve(left[k].p)) return PLONK_HIP_ERR_INVALID_POINT;
         right.push_back(make_term(proof, w));
         v_total = fe_add(v_total, fe_mul(w, v));
     }

@@ -164,3 +164,24 @@ def test_kzg_verify_like_the_reference_test():
     coms, us, vs, proofs = _arrays([(com_f, u, v, proof)])
     tau_g2 = plonk_amd.kzg_setup_tau_g2(oc.fr_to_mont([tau])[0])
     assert plonk_amd.kzg_verify(tau_g2, coms[0], us[0], vs[0], proofs[0])
+
+
+def test_points_off_the_curve_are_refused(openings, tau_g2):
+    """The reference's G1 values are on the curve by construction (validated deserialisation); raw limbs are
+    not, and a pairing of a point off the curve means nothing: PLONK_HIP_ERR_INVALID_POINT, one by one and
+    inside a fold, for the commitment and for the proof; a Z != 1 representative of a good point still passes."""
+    coms, us, vs, proofs = _arrays(openings)
+    bad = coms[4].copy()
+    bad[6] ^= np.uint64(1)  # one bit of Y
+    with pytest.raises(plonk_amd.ReferencePanic) as e:
+        plonk_amd.kzg_verify(tau_g2, bad, us[4], vs[4], proofs[4])
+    assert e.value.code == -9
+    bad_proof = proofs[4].copy()
+    bad_proof[0] ^= np.uint64(2)  # one bit of X
+    with pytest.raises(plonk_amd.ReferencePanic):
+        plonk_amd.kzg_verify(tau_g2, coms[4], us[4], vs[4], bad_proof)
+    folded = coms.copy()
+    folded[9] = bad
+    with pytest.raises(plonk_amd.ReferencePanic):
+        plonk_amd.kzg_verify_batch(tau_g2, folded, us, vs, proofs)
+    assert plonk_amd.kzg_verify_batch(tau_g2, coms, us, vs, proofs)

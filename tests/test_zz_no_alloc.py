@@ -74,3 +74,37 @@ def test_size_limit_is_an_error_not_an_allocation(backend):
         assert e.value.code == -4
     finally:
         backend.free(flag)
+
+
+def test_two_contexts_on_one_gpu_share_the_array_in_turn(backend):
+    """Two contexts on device 0 (each with a stream of its own) queue the call back to back without waiting in
+    between: the library orders their uses of the GPU's one scratch array, so both results are right."""
+    rng = np.random.default_rng(11)
+    other = plonk_amd.Backend(device=0)
+    n = (1 << 21) + 777
+    inputs = []
+    try:
+        for be in (backend, other, backend, other):
+            num, den = rand(rng, n), rand(rng, n)
+            den[den.sum(axis=1) == 0] = 1
+            inputs.append((be, num, den, be.to_device(num), be.to_device(den), be.malloc(256)))
+        for be, _, _, d_num, d_den, d_flag in inputs:  # four launches queued on two streams, no host wait
+            be.fr_ratio_prefix_product_dev_noalloc(d_num, d_den, n, d_flag)
+        backend.sync()
+        other.sync()
+        for be, num, den, d_num, d_den, d_flag in inputs:
+            got = be.from_device(d_num, (n, 4))
+            d_a, d_b = be.to_device(num), be.to_device(den)
+            be.fr_ratio_prefix_product_dev(d_a, d_b, n)
+            be.sync()
+            assert np.array_equal(got, be.from_device(d_a, (n, 4)))
+            assert int(be.from_device(d_flag, (1,), dtype=np.int32)[0]) == 0
+            be.free(d_a)
+            be.free(d_b)
+    finally:
+        backend.sync()
+        other.sync()
+        for be, _, _, d_num, d_den, d_flag in inputs:
+            for p in (d_num, d_den, d_flag):
+                be.free(p)
+        other.close()
