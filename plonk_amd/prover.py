@@ -72,6 +72,36 @@ def deal_tasks(sizes, world):
     return owner
 
 
+# What building a polynomial group costs next to a multi-scalar multiplication, in coefficients of an MSM of the
+# same duration (measured at 2^20 gates on one GPU: about 8.4 ms per d coefficients of MSM; the gate quotient
+# and the running product about 12 ms each, the wiring quotient 12 ms on top of the running product).
+BUILD_COST_IN_D = {"q3": 1.4, "t": 1.4, "q4": 1.4}
+BUILD_NEEDS = {"q3": ("q3",), "t": ("t",), "q4": ("t", "q4"), None: ()}
+
+
+def deal_tasks_by_need(sizes, needs, world, d):
+    """Owner of each task when the ranks also share the BUILDING of the polynomials: task i is an MSM over
+    sizes[i] coefficients of a polynomial of group needs[i] (None: one every rank has anyway; "q3": the gate
+    quotient; "t": the running product; "q4": the wiring quotient, which is built from t).  A rank builds only
+    the groups its own tasks need.  Largest tasks first, each to the rank whose finishing time (MSMs so far +
+    the builds it would have to add) stays lowest.  The same on every rank."""
+    load = [0.0] * world
+    built = [set() for _ in range(world)]
+    owner = [0] * len(sizes)
+
+    def added(rank, need):
+        return sum(BUILD_COST_IN_D[g] * d for g in BUILD_NEEDS[need] if g not in built[rank])
+
+    # tasks that need a group first (they pin where the groups are built), then the free ones
+    order = sorted(range(len(sizes)), key=lambda j: (needs[j] is None, -sizes[j], j))
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k] + added(k, needs[i]) + sizes[i], k))
+        load[r] += added(r, needs[i]) + sizes[i]
+        built[r].update(BUILD_NEEDS[needs[i]])
+        owner[i] = r
+    return owner
+
+
 # ------------------------------------------------------------------------------ circuit description
 class Circuit:
     """gates[l]: 1 addition, 0 multiplication; trace: (d, 4) limbs, the value on every row of Omega;
@@ -443,8 +473,10 @@ class Prover:
         """`prove` with every polynomial kept in device memory between the steps: the trace, S and W go
         up once, commitments, opened values and proofs come down; same proof, bit for bit.
         ranks: None, or an object with `world`, `rank` and `exchange(rows)` (plonk_amd.sharding.
-        TaskExchange): one process per GPU, every rank builds the polynomials, the 18 independent
-        commitments and openings are dealt out by size (`deal_tasks`) and their results gathered."""
+        TaskExchange): one process per GPU; the 18 independent commitments and openings are dealt out
+        together with the building of the polynomials they read (`deal_tasks_by_need`: a rank builds the
+        gate quotient, the running product or the wiring quotient only if one of its own tasks needs it) and
+        their results gathered."""
         import time
         clock = [time.perf_counter()]
 
@@ -528,65 +560,97 @@ class Prover:
             self.challenges = {"r2": r2, "r3": r3, "r": r, "s": s, "rp": rp}
             lap("part1")
 
-            # the polynomials of parts 2, 3 and 4
+            # The polynomials of parts 2, 3 and 4, in groups that are built only where they are needed: one
+            # process builds all of them; several processes deal the tasks out so that the gate quotient (q3),
+            # the running product (t) and the wiring quotient (q4) are each built by the few ranks whose tasks
+            # read them (deal_tasks_by_need), and the other ranks start their multi-scalar multiplications at once.
             T_minus_v = lin(T, v, 1, -1)
             q2 = pool.new(d - n_in)
             be.fr_div_by_roots_dev(T_minus_v[0], d, pool.put(rows_in)[0], n_in, q2[0])
-            T_w = shift(T, w)
-            T_w2 = shift(T, w * w % R_MOD)
-            one_minus_S = lin(S, None, -1, 0, 1)
-            S_T = lin(mul(S, lin(T, T_w, 1, 1)), mul(one_minus_S, mul(T, T_w)), 1, 1)
-            lin(S_T, T_w2, 1, -1, out=S_T)
-            q3 = pool.new(S_T[1] - ng)
-            if self._gate_rows_are_a_subgroup_less_one(ng):
-                # Z_gates (X - rho) = X^n - 1: multiply by the missing factor, divide by X^n - 1
-                n_sub, rho = ng + 1, pow(w, 3 * ng, R_MOD)
-                shifted = pool.new(S_T[1] + 1)
-                be.memset_zero(shifted[0], 32)
-                be.memcpy_d2d(shifted[0] + 32, S_T[0], S_T[1] * 32)
-                lin(shifted, S_T, 1, -rho, out=shifted)
-                be.fr_div_vanishing_dev(shifted[0], shifted[1], n_sub, q3[0])
-                rem = lin((shifted[0], n_sub), (q3[0], min(n_sub, q3[1])), 1, 1)
-                if not be.fr_is_zero_dev(rem[0], rem[1]):
-                    raise ValueError("S_T should cancel on y (prover/part3.rs:61-64)")
+            n_q3 = (ng - 1) + 2 * (d - 1) + 1 - ng   # coefficients of S_T / Z_gates
+            n_q4 = 2 * (d - 1) + 1 - d               # coefficients of t1 / (X^d - 1)
+            wr = w * r3 % R_MOD
+            # (polynomial, its length, the group it belongs to, point or None for a commitment)
+            plan = [("q2", d - n_in, None, None), ("T_minus_v", d, None, r2), ("q2", d - n_in, None, r2),
+                    ("q3", n_q3, "q3", None), ("T", d, None, r3), ("T", d, None, wr), ("T", d, None, w * wr % R_MOD),
+                    ("S", S[1], None, r3), ("q3", n_q3, "q3", r3),
+                    ("t", d, "t", None), ("q4", n_q4, "q4", None), ("t", d, "t", pow(w, d - 1, R_MOD)), ("t", d, "t", rp),
+                    ("t", d, "t", rp * w % R_MOD), ("q4", n_q4, "q4", rp),
+                    ("T", d, None, rp * w % R_MOD), ("W", W[1], None, rp * w % R_MOD), ("T", d, None, pow(w, 3 * ng - 1, R_MOD))]
+            if world > 1:
+                owner = deal_tasks_by_need([p[1] for p in plan], [p[2] for p in plan], world, d)
             else:
-                rows_gates = pool.put(self.omega[0:3 * ng:3])
-                be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
-            T_vals = copy_padded(T, d)
-            transform(T_vals, False)
-            W_vals = copy_padded(W, d)
-            transform(W_vals, False)
-            omega = pool.put(self.omega)
-            num = lin(W_vals, T_vals, -s, -1, r, broadcast=True)
-            den = lin(omega, T_vals, -s, -1, r, broadcast=True)
-            be.fr_ratio_prefix_product_dev(num[0], den[0], d)
-            t = num
-            transform(t, True)
-            if top_is_zero(t):
-                raise NotImplementedError("extra random interpolation points (protocols.rs:589-600) are not drawn here")
-            t_w = shift(t, w)
-            left = lin(pool.put(to_mont([r, (-s * w) % R_MOD])), T_w, 1, -1)
-            right = lin(shift(W, w), T_w, -s, -1, r)
-            t1 = mul(t_w, left)
-            lin(t1, mul(t, right), 1, -1, out=t1)
-            q4 = pool.new(t1[1] - d)
-            be.fr_div_vanishing_dev(t1[0], t1[1], d, q4[0])
-            rem = lin((t1[0], d), (q4[0], min(d, q4[1])), 1, 1)  # t1 = q4 X^d - q4 + remainder
-            if not be.fr_is_zero_dev(rem[0], rem[1]):
-                raise ValueError("t1 must be divisible by Z_Omega (prover/part4.rs:58)")
+                owner = [0] * len(plan)
+            mine = [i for i in range(len(plan)) if owner[i] == rank]
+            wanted = set()
+            for i in mine:
+                wanted.update(BUILD_NEEDS[plan[i][2]])
+            polys = {"q2": q2, "T_minus_v": T_minus_v, "T": T, "S": S, "W": W}
+            failure = None
+            try:
+                if "q3" in wanted:
+                    T_w = shift(T, w)
+                    T_w2 = shift(T, w * w % R_MOD)
+                    one_minus_S = lin(S, None, -1, 0, 1)
+                    S_T = lin(mul(S, lin(T, T_w, 1, 1)), mul(one_minus_S, mul(T, T_w)), 1, 1)
+                    lin(S_T, T_w2, 1, -1, out=S_T)
+                    q3 = pool.new(S_T[1] - ng)
+                    if self._gate_rows_are_a_subgroup_less_one(ng):
+                        # Z_gates (X - rho) = X^n - 1: multiply by the missing factor, divide by X^n - 1
+                        n_sub, rho = ng + 1, pow(w, 3 * ng, R_MOD)
+                        shifted = pool.new(S_T[1] + 1)
+                        be.memset_zero(shifted[0], 32)
+                        be.memcpy_d2d(shifted[0] + 32, S_T[0], S_T[1] * 32)
+                        lin(shifted, S_T, 1, -rho, out=shifted)
+                        be.fr_div_vanishing_dev(shifted[0], shifted[1], n_sub, q3[0])
+                        rem = lin((shifted[0], n_sub), (q3[0], min(n_sub, q3[1])), 1, 1)
+                        if not be.fr_is_zero_dev(rem[0], rem[1]):
+                            raise ValueError("S_T should cancel on y (prover/part3.rs:61-64)")
+                    else:
+                        rows_gates = pool.put(self.omega[0:3 * ng:3])
+                        be.fr_div_by_roots_dev(S_T[0], S_T[1], rows_gates[0], ng, q3[0])
+                    assert q3[1] == n_q3
+                    polys["q3"] = q3
+                if "t" in wanted:
+                    T_vals = copy_padded(T, d)
+                    transform(T_vals, False)
+                    W_vals = copy_padded(W, d)
+                    transform(W_vals, False)
+                    omega = pool.put(self.omega)
+                    num = lin(W_vals, T_vals, -s, -1, r, broadcast=True)
+                    den = lin(omega, T_vals, -s, -1, r, broadcast=True)
+                    be.fr_ratio_prefix_product_dev(num[0], den[0], d)
+                    t = num
+                    transform(t, True)
+                    if top_is_zero(t):
+                        raise NotImplementedError(
+                            "extra random interpolation points (protocols.rs:589-600) are not drawn here")
+                    polys["t"] = t
+                if "q4" in wanted:
+                    T_w = shift(T, w)
+                    t_w = shift(t, w)
+                    left = lin(pool.put(to_mont([r, (-s * w) % R_MOD])), T_w, 1, -1)
+                    right = lin(shift(W, w), T_w, -s, -1, r)
+                    t1 = mul(t_w, left)
+                    lin(t1, mul(t, right), 1, -1, out=t1)
+                    q4 = pool.new(t1[1] - d)
+                    be.fr_div_vanishing_dev(t1[0], t1[1], d, q4[0])
+                    rem = lin((t1[0], d), (q4[0], min(d, q4[1])), 1, 1)  # t1 = q4 X^d - q4 + remainder
+                    if not be.fr_is_zero_dev(rem[0], rem[1]):
+                        raise ValueError("t1 must be divisible by Z_Omega (prover/part4.rs:58)")
+                    assert q4[1] == n_q4
+                    polys["q4"] = q4
+            except (ValueError, NotImplementedError) as exc:
+                if world == 1:
+                    raise
+                failure = exc  # the other ranks wait in the exchange: tell them there, then raise
             be.sync()
             lap("polynomials")
 
-            # 4 commitments and 14 openings (T at w rp serves f and g), dealt out to the ranks
-            wr = w * r3 % R_MOD
-            tasks = [(q2, None), (T_minus_v, r2), (q2, r2),
-                     (q3, None), (T, r3), (T, wr), (T, w * wr % R_MOD), (S, r3), (q3, r3),
-                     (t, None), (q4, None), (t, pow(w, d - 1, R_MOD)), (t, rp), (t, rp * w % R_MOD), (q4, rp),
-                     (T, rp * w % R_MOD), (W, rp * w % R_MOD), (T, pow(w, 3 * ng - 1, R_MOD))]
-            rows = np.zeros((len(tasks), 22), dtype=np.uint64)
-            owner = deal_tasks([buf[1] for buf, _ in tasks], world)
-            mine = [i for i in range(len(tasks)) if owner[i] == rank]
-            if mine:  # one call: the multi-scalar multiplications are queued back to back
+            # 4 commitments and 14 openings (T at w rp serves f and g)
+            tasks = [(polys.get(name), point) for name, _, _, point in plan]
+            rows = np.zeros((len(tasks) + world, 22), dtype=np.uint64)
+            if mine and failure is None:  # one call: the multi-scalar multiplications are queued back to back
                 vals, points = be.kzg_commit_open_many_dev(
                     [(tasks[i][0][0], tasks[i][0][1], None if tasks[i][1] is None else _m(tasks[i][1])) for i in mine])
                 for k, i in enumerate(mine):
@@ -596,8 +660,14 @@ class Prover:
                     self._log(buf, points[k], point, None if point is None else from_mont(vals[k])[0])
             lap("commit_open")
             if world > 1:
-                rows = ranks.exchange(rows, owner)
+                rows[len(tasks) + rank, 0] = 0 if failure is None else 1
+                rows = ranks.exchange(rows, owner + list(range(world)))
                 lap("exchange")
+                if failure is not None:
+                    raise failure
+                bad = [k for k in range(world) if rows[len(tasks) + k, 0]]
+                if bad:
+                    raise ValueError("the witness failed a consistency check on rank %d" % bad[0])
             g1 = rows[:, :18]
             val = from_mont(rows[:, 18:])
             if val[17] != circuit.output % R_MOD:

@@ -98,10 +98,12 @@ def _prover_worker(rank, world, port, log_gates, out_path):
     be.close()
 
 
-@pytest.mark.parametrize("world,log_gates", [(2, 6), (3, 10)])
+@pytest.mark.parametrize("world,log_gates", [(2, 6), (3, 10), (4, 7)])
 def test_proof_shared_by_polynomial_between_ranks(tmp_path, world, log_gates):
     """The 18 independent commitments and openings of a proof dealt out to the ranks (sharing by
-    polynomial): the gathered proof equals the single-rank proof."""
+    polynomial), and with them the building of the polynomials they read (with four ranks the gate quotient
+    is built by two of them and the running product / wiring quotient by the other two): the gathered proof
+    equals the single-rank proof."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -52,3 +52,28 @@ def test_tasks_are_dealt_by_size():
     load = [sum(s for s, o_ in zip(sizes, owner) if o_ == r) for r in range(3)]
     assert sorted(load) == [17, 20, 20] and owner[3] == 0
     assert pv.deal_tasks(sizes, 3) == owner  # deterministic: every rank computes the same deal
+
+
+def test_dealing_tasks_together_with_the_polynomials_they_read():
+    """Sharing a proof between ranks: every task gets an owner, the deal is the same on every rank, one rank
+    takes everything, and from four ranks on no rank builds all three polynomial groups (the point of dealing
+    by need: the replicated building was about half of an 8-rank proof's latency)."""
+    d = 3 << 10
+    sizes = [d - 2, d, d - 2, 2 * d, d, d, d, d // 3, 2 * d, d, d - 1, d, d, d, d - 1, d, d, d]
+    needs = [None, None, None, "q3", None, None, None, None, "q3", "t", "q4", "t", "t", "t", "q4", None, None, None]
+    assert pv.deal_tasks_by_need(sizes, needs, 1, d) == [0] * 18
+    for world in (2, 3, 4, 8):
+        owner = pv.deal_tasks_by_need(sizes, needs, world, d)
+        assert owner == pv.deal_tasks_by_need(sizes, needs, world, d)
+        assert len(owner) == 18 and set(owner) <= set(range(world))
+        built = [set() for _ in range(world)]
+        load = [0.0] * world
+        for i, r in enumerate(owner):
+            built[r].update(pv.BUILD_NEEDS[needs[i]])
+            load[r] += sizes[i] / d
+        finish = [load[r] + sum(pv.BUILD_COST_IN_D[g] for g in built[r]) for r in range(world)]
+        replicated = sum(sizes) / d / world + sum(pv.BUILD_COST_IN_D.values())
+        assert max(finish) <= replicated + 0.35, (world, finish, replicated)
+        if world >= 4:
+            assert all(len(b) < 3 for b in built)
+            assert max(finish) < 0.85 * replicated
