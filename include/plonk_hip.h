@@ -301,6 +301,15 @@ int plonk_hip_fr_div_by_roots(plonk_hip_ctx *ctx, const uint64_t *f, size_t n, c
  * xs = Omega).  PLONK_HIP_ERR_ZERO_DENOMINATOR when two xs coincide (the reference panics,
  * polynomials.rs:42). */
 int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint64_t *ys, size_t n, uint64_t *coeffs);
+/* `interpolate_polynomial(x_points, y_points)` for x_points = [1, q, q^2, ..., q^(n-1)] in O(n log n) (two
+ * products of length n; no limit on n beyond the transforms'): the gate rows of a circuit are such a set
+ * (Omega[3 l] = (omega^3)^l, plonk/src/setup_proving_key/mod.rs:36-43; plonk/src/prover/part3.rs:32-33) and are a
+ * whole subgroup only for one circuit size of each family.  PLONK_HIP_ERR_ZERO_DENOMINATOR when two of the points
+ * coincide (q^k = 1 for some 0 < k < n), like the reference's panic (polynomials.rs:42).  The _dev form works in
+ * place on n values in device memory and waits for its result. */
+int plonk_hip_fr_interpolate_geometric(plonk_hip_ctx *ctx, const uint64_t q[4], const uint64_t *ys, size_t n,
+                                       uint64_t *coeffs);
+int plonk_hip_fr_interpolate_geometric_dev(plonk_hip_ctx *ctx, const uint64_t q[4], void *d_values, size_t n);
 
 /* ---- Device-resident variants ------------------------------------------------------------------
  * The polynomial entry points above copy their operands from and to host memory on every call, which

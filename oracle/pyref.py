@@ -737,15 +737,20 @@ def example_circuit(d=12):
     return Circuit([1, 1, 0], trace, wiring, [5, 6], 77)
 
 
-def synthetic_circuit(log_gates, seed):
+def synthetic_circuit(log_gates, seed, number_gates=None):
     """A random circuit of the same family at another size: 2^log_gates - 1 gates, 2 public inputs,
     1 witness, d = 3 * 2^log_gates (log_gates = 2 gives the example's shape).  Every gate takes two
     earlier values (inputs, the witness or gate outputs) and adds or multiplies them; the last
-    gate's output is the circuit's output."""
+    gate's output is the circuit's output.  number_gates: fewer gates on the same d rows (the rows between
+    the last gate and the witness stay empty: value 0, wired to themselves); the gate rows are then a
+    proper prefix of the subgroup generated by omega^3."""
     import random as _random
     rnd = _random.Random(seed)
     ng = (1 << log_gates) - 1
     d = 3 * ng + 3
+    if number_gates is not None:
+        assert 1 <= number_gates <= ng
+        ng = number_gates
     trace = [0] * d
     pool = []  # [value, positions]
     for pos in (d - 1, d - 2, d - 3):
@@ -765,7 +770,7 @@ def synthetic_circuit(log_gates, seed):
             val[1].append(pos)
         trace[3 * l + 2] = out
         pool.append([out, [3 * l + 2]])
-    wiring = [0] * d
+    wiring = list(range(d))
     for _, positions in pool:
         for i, pos in enumerate(positions):
             wiring[pos] = positions[(i + 1) % len(positions)]

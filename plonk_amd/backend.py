@@ -563,6 +563,18 @@ class Backend:
         self._check(self._lib.plonk_hip_fr_interpolate(self._ctx, _u64(xs), _u64(ys), xs.shape[0], _u64(out)))
         return out
 
+    def interpolate_geometric(self, q, ys):
+        """`interpolate_polynomial([1, q, q^2, ...], ys)` in O(n log n), untrimmed; ReferencePanic when two of
+        the points coincide."""
+        ys = _fr(ys)
+        out = np.empty_like(ys)
+        self._check(self._lib.plonk_hip_fr_interpolate_geometric(self._ctx, _u64(_fr(q).reshape(4)), _u64(ys),
+                                                                 ys.shape[0], _u64(out)))
+        return out
+
+    def interpolate_geometric_dev(self, q, d_values, n):
+        self._check(self._lib.plonk_hip_fr_interpolate_geometric_dev(self._ctx, _u64(_fr(q).reshape(4)), d_values, n))
+
     def quotient_coset(self, f):
         """Batch of polynomials with 2k coefficients each -> (q (batch, k, 4), divisible flags)."""
         f = np.ascontiguousarray(f, dtype=np.uint64)

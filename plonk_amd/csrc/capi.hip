@@ -948,6 +948,32 @@ int plonk_hip_fr_interpolate(plonk_hip_ctx *ctx, const uint64_t *xs, const uint6
     return download(ctx, coeffs, d_o, n);
 }
 
+int plonk_hip_fr_interpolate_geometric(plonk_hip_ctx *ctx, const uint64_t q[4], const uint64_t *ys, size_t n,
+                                       uint64_t *coeffs) {
+    PLONK_ENTER(ctx);
+    if (!q || ((!ys || !coeffs) && n)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    Fr *d_y;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(upload(ctx, ctx->scalars_stage, ys, n, 0, &d_y));
+    PLONK_TRY(interpolate_geometric_dev(ctx, load_fr(q), d_y, n, d_y, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    if (flag) return PLONK_HIP_ERR_ZERO_DENOMINATOR;
+    return download(ctx, coeffs, d_y, n);
+}
+
+int plonk_hip_fr_interpolate_geometric_dev(plonk_hip_ctx *ctx, const uint64_t q[4], void *d_values, size_t n) {
+    PLONK_ENTER(ctx);
+    if (!q || (!d_values && n)) return PLONK_HIP_ERR_INVALID_ARG;
+    if (n == 0) return PLONK_HIP_OK;
+    int *d_flag, flag = 0;
+    PLONK_TRY(fresh_flag(ctx, &d_flag));
+    PLONK_TRY(interpolate_geometric_dev(ctx, load_fr(q), (const Fr *)d_values, n, (Fr *)d_values, d_flag));
+    PLONK_TRY(read_flag(ctx, d_flag, &flag));
+    return flag ? PLONK_HIP_ERR_ZERO_DENOMINATOR : PLONK_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------- device-resident variants
 // The same operations on polynomials that already live in device memory (plonk_hip_malloc): nothing
 // crosses PCIe but the scalars.  Stream-ordered like every _dev entry point; the ones that hand

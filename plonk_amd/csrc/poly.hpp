@@ -43,6 +43,8 @@ int div_by_roots_dev(plonk_hip_ctx *ctx, const Fr *d_f, size_t n, const Fr *d_ro
 // interpolation at arbitrary points (quadratic work)
 static constexpr size_t kMaxInterpolationPoints = (size_t)1 << 16;
 int interpolate_dev(plonk_hip_ctx *ctx, const Fr *d_x, const Fr *d_y, size_t n, Fr *d_out, int *d_flag);
+// interpolation at the points 1, q, q^2, ...: two products of length n (any n the transforms take)
+int interpolate_geometric_dev(plonk_hip_ctx *ctx, const Fr &q, const Fr *d_y, size_t n, Fr *d_out, int *d_flag);
 
 // ntt.hip
 // butterflies only: forward = natural order in, bit-reversed order out, no scaling;

@@ -196,6 +196,8 @@ int linear_combination(plonk_hip_ctx *ctx, const Fr *x, size_t nx, const Fr *y, 
     return PLONK_HIP_OK;
 }
 
+__global__ void k_set_flag(int *flag) { *flag = 1; }
+
 // *flag |= 1 when some element is not zero
 __global__ __launch_bounds__(256) void k_any_nonzero(const Fr *__restrict__ x, size_t n, int *__restrict__ flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,6 +542,96 @@ int interpolate_dev(plonk_hip_ctx *ctx, const Fr *d_x, const Fr *d_y, size_t n, 
     PLONK_TRY(pointwise_mul(ctx, c, d_y, c, n));
     hipLaunchKernelGGL(k_lagrange_rows, dim3((unsigned)rows), dim3(64), 0, st, M, n, d_x, c, partial);
     hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, rows, n, d_out);
+    PLONK_HIP_TRY(ctx, hipGetLastError());
+    return PLONK_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// interpolation at the points 1, q, q^2, ..., q^(n-1)  (O(n log n))
+// ------------------------------------------------------------------------------------------
+// The gate rows of a circuit are such a set (Omega[3 l] = (w^3)^l, setup_proving_key/mod.rs:36-43), and it is a
+// whole subgroup -- where one inverse transform interpolates -- only for one circuit size in each family.  On a
+// geometric progression the Newton basis N_i = prod_{j<i} (X - q^j) has closed forms (the q-binomial theorem):
+// with u_i = prod_{k=1..i} (q^k - 1), e_i = q^(i(i-1)/2) and g_i = (-1)^i e_i / u_i,
+//     values -> Newton coefficients:   c_i e_i = [X^i]  (sum_j v_j / u_j X^j) * (sum_k g_k X^k)
+//     Newton -> monomial coefficients: F_k u_k = sum_{j>=0} (c_(k+j) u_(k+j)) g_j
+// i.e. two products of length n, three running products and one batched inversion.
+//
+// a[0] = 1, a[i] = v for i >= 1 (the running product is then v^i)
+__global__ __launch_bounds__(256) void k_geo_fill(Fr *__restrict__ a, size_t n, Fr v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i ? v : fe_one<FrCfg>();
+}
+// from pw[i] = q^i and pwi[i] = q^-i: the factors whose running products are u, e and 1/e
+__global__ __launch_bounds__(256) void k_geo_factors(const Fr *__restrict__ pw, const Fr *__restrict__ pwi, size_t n,
+                                                    Fr *__restrict__ u, Fr *__restrict__ e, Fr *__restrict__ einv) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr one = fe_one<FrCfg>();
+    u[i] = i ? fe_sub(pw[i], one) : one;
+    e[i] = i ? pw[i - 1] : one;
+    einv[i] = i ? pwi[i - 1] : one;
+}
+// g[i] = (-1)^i e[i] uinv[i];  w[i] = y[i] uinv[i]
+__global__ __launch_bounds__(256) void k_geo_series(const Fr *__restrict__ e, const Fr *__restrict__ uinv,
+                                                   const Fr *__restrict__ y, size_t n, Fr *__restrict__ g,
+                                                   Fr *__restrict__ w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr t = fe_mul(e[i], uinv[i]);
+    g[i] = (i & 1) ? fe_neg(t) : t;
+    w[i] = fe_mul(y[i], uinv[i]);
+}
+// a[n - 1 - i] = p[i] u[i] einv[i]   (c_i u_i, highest index first)
+__global__ __launch_bounds__(256) void k_geo_newton(const Fr *__restrict__ p, const Fr *__restrict__ u,
+                                                   const Fr *__restrict__ einv, size_t n, Fr *__restrict__ a) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[n - 1 - i] = fe_mul(p[i], fe_mul(u[i], einv[i]));
+}
+// out[k] = c[n - 1 - k] uinv[k]
+__global__ __launch_bounds__(256) void k_geo_finish(const Fr *__restrict__ c, const Fr *__restrict__ uinv, size_t n,
+                                                   Fr *__restrict__ out) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = fe_mul(c[n - 1 - k], uinv[k]);
+}
+
+// The n coefficients of the polynomial of degree < n with F(q^i) = y[i], i < n (`interpolate_polynomial` of the
+// reference, common/polynomials.rs:50-58, for x_points = [1, q, q^2, ...]).  *d_flag is set when two of the
+// points coincide (q^k = 1 for some 0 < k < n; the reference panics on the zero denominator, polynomials.rs:42).
+// d_out may be d_y.
+int interpolate_geometric_dev(plonk_hip_ctx *ctx, const Fr &q, const Fr *d_y, size_t n, Fr *d_out, int *d_flag) {
+    if (n == 0) return PLONK_HIP_OK;
+    if (n > ((size_t)1 << 28)) return PLONK_HIP_ERR_INVALID_ARG;
+    hipStream_t st = ctx->stream;
+    if (fe_is_zero(q)) {
+        // the points 1, 0, 0, ...: distinct only for n <= 2
+        if (n > 2) {
+            hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, st, d_flag);
+            return PLONK_HIP_OK;
+        }
+    }
+    const size_t scr = prefix_scan_scratch_elems(n);
+    PLONK_TRY(buf_reserve(ctx, ctx->interp_ws, (7 * n + scr) * sizeof(Fr)));
+    Fr *x0 = (Fr *)ctx->interp_ws.ptr, *x1 = x0 + n, *u = x1 + n, *e = u + n, *einv = e + n, *x5 = einv + n,
+       *x6 = x5 + n, *scratch = x6 + n;
+    const unsigned blocks = cdiv(n, 256);
+    const Fr qinv = fe_is_zero(q) ? q : fe_inv(q);
+    hipLaunchKernelGGL(k_geo_fill, dim3(blocks), dim3(256), 0, st, x0, n, q);
+    hipLaunchKernelGGL(k_geo_fill, dim3(blocks), dim3(256), 0, st, x1, n, qinv);
+    PLONK_TRY(prefix_scan(ctx, x0, n, true, scratch));  // q^i
+    PLONK_TRY(prefix_scan(ctx, x1, n, true, scratch));  // q^-i
+    hipLaunchKernelGGL(k_geo_factors, dim3(blocks), dim3(256), 0, st, x0, x1, n, u, e, einv);
+    PLONK_TRY(prefix_scan(ctx, u, n, true, scratch));
+    PLONK_TRY(prefix_scan(ctx, e, n, true, scratch));
+    PLONK_TRY(prefix_scan(ctx, einv, n, true, scratch));
+    Fr *uinv = x0, *g = x1;
+    PLONK_HIP_TRY(ctx, hipMemcpyAsync(uinv, u, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    PLONK_TRY(batch_inverse(ctx, uinv, n, d_flag));  // a zero u_i: q^k = 1 for some 0 < k <= i
+    hipLaunchKernelGGL(k_geo_series, dim3(blocks), dim3(256), 0, st, e, uinv, d_y, n, g, x5);
+    PLONK_TRY(poly_mul_dev(ctx, x5, n, g, n, x6, n));
+    hipLaunchKernelGGL(k_geo_newton, dim3(blocks), dim3(256), 0, st, x6, u, einv, n, x5);
+    PLONK_TRY(poly_mul_dev(ctx, x5, n, g, n, x6, n));
+    hipLaunchKernelGGL(k_geo_finish, dim3(blocks), dim3(256), 0, st, x6, uinv, n, d_out);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }

@@ -132,6 +132,8 @@ SIGNATURES = {
     "plonk_hip_fr_div_by_roots": (
         ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, c_u64p, ctypes.c_size_t, c_u64p]),
     "plonk_hip_fr_interpolate": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_interpolate_geometric": (ctypes.c_int, [c_ctx, c_u64p, c_u64p, ctypes.c_size_t, c_u64p]),
+    "plonk_hip_fr_interpolate_geometric_dev": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_hip_multi_create": (ctypes.c_int, [c_intp, ctypes.c_int, ctypes.POINTER(c_ctx)]),
     "plonk_hip_multi_destroy": (None, [c_ctx]),
     "plonk_hip_multi_last_error": (ctypes.c_char_p, [c_ctx]),

@@ -131,13 +131,18 @@ def example_circuit():
     return Circuit([1, 1, 0], to_mont([5, 6, 11, 6, 1, 7, 11, 7, 77, 1, 6, 5]), wiring, [5, 6], 77)
 
 
-def synthetic_circuit(log_gates, seed):
+def synthetic_circuit(log_gates, seed, number_gates=None):
     """A random circuit of the example's family: 2^log_gates - 1 gates, 2 public inputs, 1 witness,
-    d = 3 * 2^log_gates rows.  Every gate adds or multiplies two earlier values."""
+    d = 3 * 2^log_gates rows.  Every gate adds or multiplies two earlier values.  number_gates: fewer gates on
+    the same rows (the rows between the last gate and the witness stay empty: value 0, wired to themselves)."""
     import random
     rnd = random.Random(seed)
     ng = (1 << log_gates) - 1
     d = 3 * ng + 3
+    if number_gates is not None:
+        if not 1 <= number_gates <= ng:
+            raise ValueError("number_gates out of range")
+        ng = number_gates
     trace = [0] * d
     values, positions = [], []
     for pos in (d - 1, d - 2, d - 3):
@@ -158,7 +163,7 @@ def synthetic_circuit(log_gates, seed):
         trace[3 * l + 2] = out
         values.append(out)
         positions.append([3 * l + 2])
-    wiring = [0] * d
+    wiring = list(range(d))
     for plist in positions:
         for i, pos in enumerate(plist):
             wiring[pos] = plist[(i + 1) % len(plist)]
@@ -370,14 +375,16 @@ class Prover:
     # -- setup_proving_key / setup_verification_key ------------------------------------------
     def selector(self, circuit):
         """S = interpolate(Omega_gates, gates), degree < number_gates (setup_proving_key/mod.rs:36-43).
-        The gate rows Omega[3l] lie in the subgroup generated by w^3; when they are all of it but
-        one row (the family of the example) the missing value is the one that makes the top
-        coefficient of the subgroup interpolant vanish, and one inverse transform gives S."""
+        The gate rows Omega[3l] = (w^3)^l are a geometric progression: any number of them is interpolated in
+        O(n log n) by `interpolate_geometric`.  When they are all of the subgroup generated by w^3 but one row
+        (the family of the example) the missing value is the one that makes the top coefficient of the subgroup
+        interpolant vanish, and one inverse transform gives S."""
         ng, d = circuit.number_gates, self.d
         n = ng + 1
         if d % 3 or d // 3 != n or n & (n - 1):
-            xs = self.omega[0:3 * ng:3]
-            return trim(self.be.interpolate_polynomial(xs, to_mont([int(g) for g in circuit.gates])))
+            values = np.zeros((ng, 4), dtype=np.uint64)
+            values[circuit.gates != 0] = self.one
+            return trim(self.be.interpolate_geometric(_m(pow(self.w, 3, R_MOD)), values))
         w3 = pow(self.w, 3, R_MOD)
         powers = self.be.compose_with_scaling(np.tile(self.one, (n, 1)), _m(w3))
         values = np.zeros((n, 4), dtype=np.uint64)

@@ -239,3 +239,45 @@ def test_quotient_by_2_20_gate_roots(backend):
     assert np.array_equal(got, q_star)
     f[:m] = c.fr_add(f[:m].copy(), _rand_mont(rng, m))  # a remainder of degree < m
     assert np.array_equal(backend.compute_q_zero_test_from_roots(roots, f), q_star)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 33, 100, 1000])
+def test_interpolation_on_a_geometric_progression(backend, n):
+    """`interpolate_polynomial([1, q, q^2, ...], ys)` (polynomials.rs:50-58) in O(n log n): the same coefficients as
+    the restatement's Lagrange form, for q a root of unity of large order (the gate rows, q = omega^3) and for a
+    random q."""
+    rnd = random.Random(700 + n)
+    for q in (pow(7, (o.R - 1) // (3 << 20), o.R), rnd.randrange(2, o.R)):
+        ys = rand_fr(rnd, n)
+        xs = [pow(q, i, o.R) for i in range(n)]
+        got = backend.interpolate_geometric(c.fr_to_mont([q])[0], c.fr_to_mont(ys))
+        want = o.interpolate_polynomial(xs, ys)
+        assert c.fr_from_mont(got) == want + [0] * (n - len(want))
+        # the general entry point agrees
+        assert np.array_equal(got, backend.interpolate_polynomial(c.fr_to_mont(xs), c.fr_to_mont(ys)))
+
+
+def test_interpolation_on_a_geometric_progression_large_and_degenerate(backend):
+    rnd = random.Random(800)
+    # beyond the 2^16 points of the quadratic kernel: checked at sampled points by the oracle's Horner evaluation
+    n = (1 << 17) + 12345
+    q = pow(7, (o.R - 1) // (3 << 18), o.R)
+    ys = c.fr_to_mont(rand_fr(rnd, n))
+    coeffs = backend.interpolate_geometric(c.fr_to_mont([q])[0], ys)
+    for i in [0, 1, 2, n // 2, n - 2, n - 1] + [rnd.randrange(n) for _ in range(10)]:
+        assert np.array_equal(c.fr_eval(coeffs, c.fr_to_mont([pow(q, i, o.R)])[0]), ys[i]), i
+    # points that coincide: q of order 8 and nine points; q = 1; q = 0 with three points
+    with pytest.raises(plonk_amd.ReferencePanic):
+        backend.interpolate_geometric(c.fr_to_mont([pow(7, (o.R - 1) // 8, o.R)])[0], c.fr_to_mont(rand_fr(rnd, 9)))
+    with pytest.raises(plonk_amd.ReferencePanic):
+        backend.interpolate_geometric(c.fr_to_mont([1])[0], c.fr_to_mont(rand_fr(rnd, 2)))
+    with pytest.raises(plonk_amd.ReferencePanic):
+        backend.interpolate_geometric(c.fr_to_mont([0])[0], c.fr_to_mont(rand_fr(rnd, 3)))
+    # eight points on the subgroup of order 8 are fine: the interpolant is the inverse transform
+    w8 = pow(7, (o.R - 1) // 8, o.R)
+    ys8 = c.fr_to_mont(rand_fr(rnd, 8))
+    assert np.array_equal(backend.interpolate_geometric(c.fr_to_mont([w8])[0], ys8), backend.fr_ntt(ys8, inverse=True))
+    # two points 1, 0
+    two = rand_fr(rnd, 2)
+    got = c.fr_from_mont(backend.interpolate_geometric(c.fr_to_mont([0])[0], c.fr_to_mont(two)))
+    assert got == [two[1], (two[0] - two[1]) % o.R]

@@ -208,6 +208,59 @@ def test_limb_array_prover_matches_the_restatement(backend, log_gates):
     assert p.audit_with_tau(tau) == 20
 
 
+@pytest.mark.parametrize("log_gates,number_gates", [(3, 4), (3, 5), (4, 9), (5, 30)])
+def test_circuits_whose_gate_rows_are_a_proper_prefix_of_their_subgroup(backend, log_gates, number_gates):
+    """Any number of gates on d = 3 * 2^k rows: the gate rows Omega[3l], l < number_gates, are then neither the
+    subgroup generated by w^3 nor one short of it, so the selector comes from the interpolation on a geometric
+    progression and the gate quotient from the division by the product of the root factors.  Keys and proof
+    equal the restatement's (plonk/src/setup_proving_key/mod.rs:32-103, plonk/src/prover/part3.rs:32-66), on
+    both paths of the prover."""
+    from plonk_amd import prover as pv
+    oc = o.synthetic_circuit(log_gates, 31, number_gates=number_gates)
+    d = len(oc.trace)
+    tau = 0x13579BDF02468ACE + number_gates
+    circuit = pv.synthetic_circuit(log_gates, 31, number_gates=number_gates)
+    assert np.array_equal(circuit.trace, pv.to_mont(oc.trace)) and list(circuit.wiring) == list(oc.wiring)
+    p = pv.Prover(backend, d)
+    p.setup(tau)
+    keys = p.keys(circuit)
+    setup = o.Setup(number_gates, 2, 1, d, o.kzg_setup_with_tau(2 * d - 3, tau))
+    pk, vk = o.reproduce_proving_key(setup, oc), o.reproduce_verification_key(setup, oc)
+    assert [o.fr_to_string(x) for x in pv.from_mont(keys["S"])] == pk["S"][:len(keys["S"])]
+    assert all(int(x) == 0 for x in pk["S"][len(keys["S"]):])
+    assert [o.fr_to_string(x) for x in pv.from_mont(keys["W"])] == pk["W"]
+    assert {"com_S": p.hex_of(keys["com_S"]), "com_W": p.hex_of(keys["com_W"])} == vk
+    want = o.reproduce_proof(setup, pk, vk, oc)
+    assert p.prove(circuit, keys) == want
+    assert p.prove_resident(circuit, keys) == want
+
+
+def test_a_hundred_thousand_gates_on_rows_for_131071(backend):
+    """Beyond the 2^16 points of the quadratic interpolation: 100 000 gates on d = 3 * 2^17 rows.  No restatement
+    finishes at this size; the proof is checked as in the full-size test: every commitment and opening against
+    the trapdoor, the verifier's field equations, and the openings by pairings with the public parameters."""
+    import plonk_amd
+    from plonk_amd import prover as pv
+    circuit = pv.synthetic_circuit(17, 5, number_gates=100000)
+    p = pv.Prover(backend, circuit.d)
+    tau = 0x1F2E3D4C5B6A7988
+    p.setup(tau)
+    keys = p.keys(circuit)
+    assert keys["S"].shape[0] <= 100000
+    # S takes the gate kinds on the gate rows (evaluated over the subgroup generated by w^3, zero padded)
+    n_sub = circuit.d // 3
+    padded = np.zeros((n_sub, 4), dtype=np.uint64)
+    padded[:keys["S"].shape[0]] = keys["S"]
+    on_rows = backend.fr_ntt(padded)[:100000]
+    assert np.array_equal(on_rows[circuit.gates != 0], np.tile(p.one, (int((circuit.gates != 0).sum()), 1)))
+    assert not on_rows[circuit.gates == 0].any()
+    p.kzg_log = []
+    proof = p.prove_resident(circuit, keys)
+    assert p.audit_with_tau(tau) == 20
+    assert p.check_identities((circuit.number_gates, circuit.pub_inputs), proof, keys)
+    assert p.verify_openings(plonk_amd.kzg_setup_tau_g2(pv.to_mont([tau])[0]))
+
+
 def test_limb_array_prover_rejects_what_the_reference_asserts(backend):
     """A wrong gate output, a broken wiring and a wrong claimed output stop the prover where the reference's
     assertions do (prover/part3.rs:61-64, part4.rs:36-42, part5.rs:23-26), on both paths."""
