@@ -38,6 +38,16 @@ int plonk_hip_bench_gather_rate(plonk_hip_ctx *ctx, size_t table_bytes, double *
  * when the context was created found the lanes of an instruction served in ascending order), 0 = the
  * ballot form that relies on nothing (the check failed, or PLONK_HIP_SORT_RANK=ballot was set). */
 int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx);
+/* What batch-affine bucket additions would cost (a design probe, not a product path): every lane of 512 blocks
+ * of 256 keeps accumulators_per_lane (1, 2 or 4) affine accumulators in registers and adds one point of the
+ * context's SRS (its first 4096 points, which must be loaded) to each per step; the denominators of a block share
+ * ONE field inversion through product scans in LDS (Montgomery's trick), so that an addition costs 6 field
+ * products plus its share of the scans and of the inversion.  invert = 0 skips the inversion (wrong points, same
+ * work otherwise): the scheme priced as if inversions were free.  adds_per_second: whole GPU.  first_block_out
+ * (may be NULL): the first block's 256 * accumulators_per_lane accumulators after `steps` steps as Jacobian
+ * points (x 18 limbs), for checking against an independent sum. */
+int plonk_hip_bench_batch_affine(plonk_hip_ctx *ctx, int accumulators_per_lane, int steps, int invert,
+                                 double *adds_per_second, uint64_t *first_block_out);
 /* Fault injection for the tests of the library's self-checks: with on != 0 the commitments of this context
  * skip their bucket sort, so the accumulation meets keys that are not in ascending order, which it must report
  * (PLONK_HIP_ERR_INTERNAL at the next wait) instead of returning a wrong point. */

@@ -177,6 +177,15 @@ class Backend:
         "ballot" for the form that relies on nothing."""
         return "add" if self._lib.plonk_hip_bench_sort_rank_mode(self._ctx) else "ballot"
 
+    def bench_batch_affine(self, accumulators_per_lane, steps, invert=True, want_points=False):
+        """Additions per second of the batch-affine probe (plonk_hip_bench_batch_affine); with want_points also the
+        first block's accumulators, (256 * accumulators_per_lane, 18) limbs."""
+        v = ctypes.c_double()
+        pts = np.empty((256 * accumulators_per_lane, 18), dtype=np.uint64) if want_points else None
+        self._check(self._lib.plonk_hip_bench_batch_affine(self._ctx, accumulators_per_lane, steps, 1 if invert else 0,
+                                                           ctypes.byref(v), _u64(pts) if want_points else None))
+        return (v.value, pts) if want_points else v.value
+
     def debug_skip_sort(self, on):
         """Fault injection for the tests: commitments skip their bucket sort (the accumulation must then report
         keys out of order instead of returning a wrong point)."""
