@@ -11,8 +11,8 @@ OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 MSM="$ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
-NTT="$ROOT/bench.py --workload ntt --steps 3 --warmup 1"
-QUO="$ROOT/bench.py --workload quotient --steps 3 --warmup 1"
+NTT="$ROOT/bench.py --workload ntt --steps 20 --warmup 2"
+QUO="$ROOT/bench.py --workload quotient --steps 10 --warmup 2"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS GRBM_GUI_ACTIVE GRBM_COUNT"
 
@@ -33,6 +33,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 # the headline command alone (2^24 commitments only): its per-kernel averages are per 2^24 launch
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_msm -- \
     python3 $MSM > $OUT/prof_${TAG}_stats_msm.log 2>&1 || exit 1
+# the transform and quotient workloads alone: their pass kernels' averages are per launch of THAT workload
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_ntt -- \
+    python3 $NTT > $OUT/prof_${TAG}_stats_ntt.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_quo -- \
+    python3 $QUO > $OUT/prof_${TAG}_stats_quo.log 2>&1 || exit 1
 pass msm_sq1 "$SQ1" $MSM
 pass msm_sq2 "$SQ2" $MSM
 pass msm_fetch FETCH_SIZE $MSM
