@@ -191,6 +191,11 @@ class Backend:
         keys out of order instead of returning a wrong point)."""
         self._check(self._lib.plonk_hip_bench_skip_sort(self._ctx, 1 if on else 0))
 
+    def bench_msm_tuning(self, seg_len=0):
+        """Measurement override of the accumulation's segment length (plonk_hip_bench_msm_tuning); 0 restores the
+        library's own choice."""
+        self._check(self._lib.plonk_hip_bench_msm_tuning(self._ctx, seg_len))
+
     def bench_gather_rate(self, table_bytes):
         v = ctypes.c_double()
         self._check(self._lib.plonk_hip_bench_gather_rate(self._ctx, table_bytes, ctypes.byref(v)))

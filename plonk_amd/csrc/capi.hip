@@ -133,6 +133,9 @@ int plonk_hip_ctx_create(int device, plonk_hip_ctx **out) {
         delete ctx;
         return PLONK_HIP_ERR_HIP;
     }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        ctx->num_cus = cus;
     for (int i = 0; i <= PH_COUNT; i++) {
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) {
             delete ctx;
@@ -566,6 +569,12 @@ int plonk_hip_bench_sort_rank_mode(plonk_hip_ctx *ctx) { return ctx && ctx->lds_
 int plonk_hip_bench_skip_sort(plonk_hip_ctx *ctx, int on) {
     if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
     ctx->debug_skip_sort = on != 0;
+    return PLONK_HIP_OK;
+}
+
+int plonk_hip_bench_msm_tuning(plonk_hip_ctx *ctx, uint32_t seg_len) {
+    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+    ctx->tune_seg_len = seg_len;
     return PLONK_HIP_OK;
 }
 

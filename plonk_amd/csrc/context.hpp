@@ -58,6 +58,7 @@ struct TailSlotBufs {
 
 struct plonk_hip_ctx {
     int device = 0;
+    int num_cus = 256;  // compute units of the device (read when the context is created)
     hipStream_t stream = nullptr;
     std::string last_error;
     std::recursive_mutex mu;  // serialises the entry points that use this context
@@ -68,6 +69,8 @@ struct plonk_hip_ctx {
     // the sort ranks keys with one LDS add-with-return each (checked by sort_selftest when the context is created;
     // PLONK_HIP_SORT_RANK=ballot keeps the form that relies on nothing)
     bool lds_rank_in_lane_order = false;
+    // measurement override (plonk_hip_bench_msm_tuning): segment length of the accumulation (0: the library's choice)
+    uint32_t tune_seg_len = 0;
     bool debug_skip_sort = false;  // fault injection (plonk_hip_bench_skip_sort): hand the accumulation unsorted pairs
 
     // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form

@@ -153,13 +153,8 @@ __device__ __forceinline__ G1Affine28 read_line(const uint4 *buf, uint32_t lane)
 // Two waves per SIMD: the whole addition then lives in registers.  A third wave (168 registers)
 // spills about 60 bytes per lane and iteration, which showed up as 13 GB of write traffic per
 // 2^24-point launch and cost more than the extra wave hid.
-//
-// STAGED (seg_len a multiple of 16): a lane's (bucket, entry) pairs come in through LDS sixteen
-// positions at a time (one 64-byte piece of each array per lane); fetched one position at a time
-// their cache lines are evicted and fetched again several times over a segment.
-static constexpr uint32_t kStage = 16;
-
-template <bool STAGED>
+// A lane fetches its (bucket, entry) pairs one position at a time, two positions ahead of the addition.  Bringing
+// them in sixteen at a time through LDS measured 2 to 3 % slower from 2^19 points up and the same below.
 __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
@@ -167,10 +162,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
                                                        G1Xyzz28 *__restrict__ buckets,
                                                        G1Xyzz28 *__restrict__ part, uint32_t *status) {
     __shared__ uint4 line_buf[kBlock / 64][64 * 8];                           // 8 KiB per wave
-    __shared__ uint32_t pair_buf[STAGED ? kBlock / 64 : 1][2][kStage][64];   // 8 KiB per wave
     const uint32_t lane = threadIdx.x & 63;
     uint4 *buf = line_buf[threadIdx.x >> 6];
-    uint32_t(*pairs)[kStage][64] = pair_buf[STAGED ? threadIdx.x >> 6 : 0];
     const size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nvalid = start[nbuckets];
     const size_t begin64 = seg * seg_len;
@@ -181,53 +174,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     const size_t end64 = begin64 + seg_len;
     const uint32_t end = live ? (end64 < nvalid ? (uint32_t)end64 : nvalid) : 0u;
 
-    // sixteen positions of both arrays, global memory -> registers -> LDS
-    uint4 ck[4], cv[4];
-    auto chunk_load = [&](uint32_t first) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            ck[q] = make_uint4(0, 0, 0, 0);
-            cv[q] = make_uint4(0, 0, 0, 0);
-            if (first < end) {
-                ck[q] = reinterpret_cast<const uint4 *>(keys + first)[q];
-                cv[q] = reinterpret_cast<const uint4 *>(vals + first)[q];
-            }
-        }
-    };
-    auto chunk_store = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            pairs[0][4 * q + 0][lane] = ck[q].x;
-            pairs[0][4 * q + 1][lane] = ck[q].y;
-            pairs[0][4 * q + 2][lane] = ck[q].z;
-            pairs[0][4 * q + 3][lane] = ck[q].w;
-            pairs[1][4 * q + 0][lane] = cv[q].x;
-            pairs[1][4 * q + 1][lane] = cv[q].y;
-            pairs[1][4 * q + 2][lane] = cv[q].z;
-            pairs[1][4 * q + 3][lane] = cv[q].w;
-        }
-    };
     // pair at position begin + o (zeros behind the segment's end)
     auto pair_at = [&](uint32_t o, uint32_t &key, uint32_t &val) {
         key = 0;
         val = 0;
         if (begin + o < end) {
-            if (STAGED) {
-                key = pairs[0][o & (kStage - 1)][lane];
-                val = pairs[1][o & (kStage - 1)][lane];
-            } else {
-                key = keys[begin + o];
-                val = vals[begin + o];
-            }
+            key = keys[begin + o];
+            val = vals[begin + o];
         }
     };
 
     // (bucket, entry) of the current position and of the next one; the line of the current
     // position is always on its way to (or in) the wave's buffer
-    if (STAGED) {
-        chunk_load(begin);
-        chunk_store();
-    }
     uint32_t k, v, kn, vn;
     pair_at(0, k, v);
     pair_at(1, kn, vn);
@@ -235,7 +193,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     uint32_t cur = k;
     uint32_t run_begin = begin;
     G1Xyzz28 acc = xyzz28_identity();
-    bool staged_pending = false;
     // The bucket bounds are only meaningful for keys in ascending order; a sort that lost it (see sort.hip on
     // what its ranks rely on) is reported, not trusted: every change of key is checked, and the segment's first
     // key against the one before it.
@@ -243,8 +200,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     for (uint32_t it = 0; it < seg_len; it++) {  // the same trip count for every lane of the grid
         const uint32_t p = begin + it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this position's lines have landed
-        // the pairs at positions it and it + 1 are in registers: the staged sixteen can be replaced
-        if (STAGED && staged_pending) chunk_store();
         G1Affine28 pt = read_line(buf, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane holds its line: the buffer is free
         issue_lines(table, buf, lane, vn & 0x7fffffffu);
@@ -275,10 +230,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         v = vn;
         kn = k2;
         vn = v2;
-        // the next iteration reads position it + 3: fetch its sixteen now if it opens a new group
-        // (the loads complete with the wait at the top of the loop)
-        staged_pending = STAGED && ((it + 3) & (kStage - 1)) == 0 && it + 3 < seg_len;
-        if (staged_pending) chunk_load(begin + it + 3);
     }
     if (live && cur < nbuckets) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
     if (out_of_order) __hip_atomic_store(status, kStatusKeysOutOfOrder, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -901,7 +852,14 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     const double fill = std::min(std::ceil((double)total / 262144.0),
                                  std::max(32.0, std::ceil((double)total / 1048576.0)));
     uint32_t seg_len = (uint32_t)std::max<double>(1.0, std::max(std::ceil(std::sqrt(per_bucket)), fill));
-    if (seg_len >= 32) seg_len = (seg_len + kStage - 1) / kStage * kStage;  // staged pair loads need whole groups
+    // With a few rounds of resident lanes the last round's fill shows: the shortest length that fills a whole
+    // number of rounds is taken.
+    const double resident = (double)ctx->num_cus * 4 * 2 * 64;
+    const double rounds = (double)total / seg_len / resident;
+    if (rounds >= 1.5 && rounds <= 16.0) {
+        seg_len = (uint32_t)std::ceil((double)total / (std::floor(rounds + 0.5) * resident));
+    }
+    if (ctx->tune_seg_len) seg_len = ctx->tune_seg_len;
     const size_t nseg = (total + seg_len - 1) / seg_len;
 
     // A deferred tail (overlap) takes the next free slot; anything else first finishes what is pending
@@ -911,10 +869,10 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     const int slot = ctx->npending;
 
     size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
-    PLONK_TRY(buf_reserve(ctx, ctx->keys_a, (total + kStage) * 4));  // staged loads read whole groups
-    PLONK_TRY(buf_reserve(ctx, ctx->keys_b, (total + kStage) * 4));  // staged loads read whole groups
-    PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + kStage) * 4));  // staged loads read whole groups
-    PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + kStage) * 4));  // staged loads read whole groups
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_a, (total + 16) * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->keys_b, (total + 16) * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + 16) * 4));
+    PLONK_TRY(buf_reserve(ctx, ctx->vals_b, (total + 16) * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->sort_tmp, tmp_bytes));
     DevBuf &b_start = slot ? ctx->tail_bufs[slot - 1].bucket_start : ctx->bucket_start;
     DevBuf &b_buckets = slot ? ctx->tail_bufs[slot - 1].buckets : ctx->buckets;
@@ -990,13 +948,8 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, cap, chunk_parts, queue, max_joins,
                        max_items, max_slots, ctx->status_dev);
     record(ctx, PH_ACCUM);
-    if (seg_len % kStage == 0) {
-        hipLaunchKernelGGL(k_accumulate<true>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb,
-                           seg_len, table, buckets, part, ctx->status_dev);
-    } else {
-        hipLaunchKernelGGL(k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start,
-                           nb, seg_len, table, buckets, part, ctx->status_dev);
-    }
+    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb, seg_len,
+                       table, buckets, part, ctx->status_dev);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     TailDesc &d = ctx->pending[slot];
     d.start = start;
