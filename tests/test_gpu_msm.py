@@ -269,6 +269,36 @@ def test_commit_2_16_points(backend):
     backend.free(d_out)
 
 
+@pytest.mark.parametrize("window_bits", [0, 9])
+def test_commit_at_every_kind_of_segment_length(backend, window_bits):
+    """The accumulation cuts the sorted (bucket, entry) list into segments of one length per commitment, which
+    the library fits to the lanes the device keeps resident (any value from 1 up, odd ones included).  The
+    measurement override walks lengths the fit would not pick at this size: one position per lane, odd and even
+    short ones, powers of two, one longer than the whole list of a window.  commit(f) == [f(tau)]G
+    (plonk/tests/kzg_tests.rs:36-69) for uniform scalars and for a set with two long buckets per window."""
+    rnd = random.Random(31 + window_bits)
+    n = 1 << 16
+    g = c.g1_generator()
+    tau = c.fr_to_mont([rnd.randrange(1, o.R)])[0]
+    backend.set_window_bits(window_bits)
+    backend.kzg_setup(tau, n - 1, want_points=False)
+    uniform = np.frombuffer(rnd.randbytes(n * 32), dtype=np.uint64).reshape(n, 4).copy()
+    uniform[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    two = np.tile(c.fr_to_mont([rnd.randrange(o.R)])[0], (n, 1))
+    two[(np.arange(n) // 777) % 2 == 1] = c.fr_to_mont([rnd.randrange(o.R)])[0]
+    want = {"uniform": c.g1_mul(g, c.fr_eval(uniform, tau)), "two": c.g1_mul(g, c.fr_eval(two, tau))}
+    try:
+        for seg_len in (1, 2, 3, 7, 16, 30, 31, 32, 33, 255, 256, 1000, 70001):
+            backend.bench_msm_tuning(seg_len)
+            assert same_point(backend.kzg_commit(uniform), want["uniform"]), seg_len
+            assert same_point(backend.kzg_commit(two), want["two"]), seg_len
+            both = backend.kzg_commit_batch([uniform, two])
+            assert same_point(both[0], want["uniform"]) and same_point(both[1], want["two"]), seg_len
+    finally:
+        backend.bench_msm_tuning(0)
+        backend.set_window_bits(0)
+
+
 def test_commit_2_20_points_known_answer(backend):
     rnd = random.Random(6)
     n = 1 << 20
