@@ -634,6 +634,57 @@ __global__ __launch_bounds__(256) void k_row_col_sums_coop(TailBatch tb, uint32_
     if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
 }
 
+// Large bucket arrays: the sums in two levels.  With one wave per row or column the strided part of a sum is a
+// chain of L / 64 (or H / 64) dependent additions and the H + L waves are neither few enough to run at once nor
+// many enough to even out.  Level 1 puts one lane on every m buckets instead: lane (h, j) of the first H * L / m
+// adds up B[h][j], B[h][j + L/m], ... (m terms of row h), lane (k, l) of the second H * L / m adds up B[k][l],
+// B[k + H/m][l], ... (m terms of column l); neighbouring lanes read neighbouring buckets, every lane is busy for
+// the whole chain, and m is chosen so that the grid is about what the device keeps resident.  Level 2 is the
+// one-wave-per-sum kernel over the L / m partials of a row and the H / m partials of a column.
+// Workspace (behind the bit sums): RP[H][L/m], then CP[H/m][L].
+__device__ __forceinline__ size_t reduce_partials_offset(uint32_t H, uint32_t L) {
+    return (size_t)H + L + (uint32_t)(__ffs((int)H) - 1) + (uint32_t)(__ffs((int)L) - 1) + 1;  // R, C, bit sums
+}
+
+__global__ __launch_bounds__(128, 2) void k_row_col_partials(TailBatch tb, uint32_t H, uint32_t L, uint32_t m) {
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    const G1Xyzz28 *__restrict__ B = (const G1Xyzz28 *)d.buckets;
+    G1Xyzz28 *__restrict__ P = (G1Xyzz28 *)d.red + reduce_partials_offset(H, L);
+    const uint32_t per_kind = H * (L / m);  // = (H / m) * L
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * per_kind) return;
+    const G1Xyzz28 *src;
+    size_t stride;
+    if (i < per_kind) {
+        const uint32_t lr = L / m, h = i / lr, j = i % lr;
+        src = B + (size_t)h * L + j;
+        stride = lr;
+    } else {
+        src = B + (i - per_kind);
+        stride = (size_t)(H / m) * L;
+    }
+    G1Xyzz28 acc = src[0];
+#pragma unroll 1
+    for (uint32_t t = 1; t < m; t++) acc = add_inline(acc, src[t * stride]);
+    P[i] = acc;
+}
+
+// blocks [0, H): row sums over RP; blocks [H, H + L): column sums over CP
+__global__ __launch_bounds__(kTreeBlock) void k_row_col_sums_of_partials(TailBatch tb, uint32_t H, uint32_t L, uint32_t m) {
+    __shared__ G1Xyzz28 sh[kTreeBlock / 64];
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    G1Xyzz28 *__restrict__ R = (G1Xyzz28 *)d.red, *__restrict__ C = R + H;
+    const G1Xyzz28 *__restrict__ RP = R + reduce_partials_offset(H, L), *__restrict__ CP = RP + (size_t)H * (L / m);
+    const uint32_t i = blockIdx.x;
+    const bool row = i < H;
+    const G1Xyzz28 *base = row ? RP + (size_t)i * (L / m) : CP + (i - H);
+    const size_t stride = row ? 1 : L;
+    G1Xyzz28 acc = block_sum(row ? L / m : H / m, sh, [&](uint32_t j) { return base + (size_t)j * stride; });
+    if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
+}
+
 // block i < lbits: T_i over C; lbits <= i < lbits + hbits: T_i over R; block lbits + hbits: T_all
 __global__ __launch_bounds__(256) void k_bit_sums(TailBatch tb, uint32_t hbits, uint32_t lbits) {
     __shared__ CoopMem mem;
@@ -773,9 +824,13 @@ int g1_sum_dev(plonk_hip_ctx *ctx, const G1Jac *d_pts, size_t n, G1Jac *d_out) {
 size_t msm_bucket_bytes() { return sizeof(G1Xyzz28); }
 
 // Elements of reduction workspace one MSM needs: row sums, column sums, bit sums.
+// Buckets per lane of the first level of the two-level row and column sums (0: one level).
+static uint32_t reduce_partial_terms(uint32_t sbits) { return sbits >= 18 ? 1u << (sbits - 16) : 0u; }
+
 static size_t reduce_ws_elems(uint32_t sbits) {
     const uint32_t lbits = (sbits + 1) / 2, hbits = sbits - lbits;
-    return ((size_t)1 << hbits) + ((size_t)1 << lbits) + sbits + 1;
+    const uint32_t m = reduce_partial_terms(sbits);
+    return ((size_t)1 << hbits) + ((size_t)1 << lbits) + sbits + 1 + (m ? 2 * (((size_t)1 << sbits) / m) : 0);
 }
 
 // For every MSM of the batch with a result pointer: S = sum_b (first + b + 1) B[b] over its 2^sbits
@@ -791,7 +846,12 @@ static int reduce_buckets(plonk_hip_ctx *ctx, const TailBatch &tb, uint32_t coun
     const uint32_t sums = H + L;
     const size_t all_sums = (size_t)sums * count;
     const uint32_t width = all_sums >= 1024 ? 64u : 128u;
-    if (all_sums <= 512) {  // (at 512 sums: 0.60 against 0.62 ms for the whole reduction of 2^16 buckets)
+    const uint32_t m = reduce_partial_terms(sbits);
+    if (m) {
+        const uint32_t lanes = 2 * ((1u << sbits) / m);
+        hipLaunchKernelGGL(k_row_col_partials, dim3(lanes / 128, count), dim3(128), 0, st, tb, H, L, m);
+        hipLaunchKernelGGL(k_row_col_sums_of_partials, dim3(sums, count), dim3(64), 0, st, tb, H, L, m);
+    } else if (all_sums <= 512) {  // (at 512 sums: 0.60 against 0.62 ms for the whole reduction of 2^16 buckets)
         hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums, count), dim3(256), 0, st, tb, H, L);
     } else {
         hipLaunchKernelGGL(k_row_col_sums, dim3(sums, count), dim3(width), 0, st, tb, H, L);
