@@ -177,10 +177,10 @@ int sort_pairs_passes(int end_bit);
 // result in (keys_b, vals_b) after an odd number of passes, in (keys_a, vals_a) after an even one.
 int sort_pairs(plonk_hip_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n,
                int end_bit, void *temp, size_t temp_bytes);
-// The same sort with the first pass made from the scalars (the pairs of scalar i: window w -> key = |digit| - 1
-// or nbuckets for digit 0, val = w * srs_n + first + i with the sign in bit 31); temp as for
-// sort_pairs(n * nwin pairs); result where sort_pairs leaves it.
-bool sort_pairs_of_scalars_applies(size_t n, int end_bit, int nwin);
+// The same sort, by the c - 1 bucket bits of the keys, with the first pass made from the scalars (the pairs of
+// scalar i: window w -> key = |digit| - 1 or nbuckets for digit 0, val = w * srs_n + first + i with the sign in
+// bit 31); temp as for sort_pairs(n * nwin pairs, c - 1); result where sort_pairs leaves it.
+bool sort_pairs_of_scalars_applies(size_t n, int c, int nwin);
 int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, size_t srs_n, size_t first, int c, int nwin,
                           uint32_t nbuckets, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                           void *temp, size_t temp_bytes);

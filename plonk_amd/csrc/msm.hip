@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
     for (int w = 0; w < nwin; w++) {
         int32_t d = signed_digit(k, w, c, carry);
         uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        // digit 0 contributes nothing: key nbuckets sorts behind every real bucket
+        // digit 0 contributes nothing: key nbuckets, which the sort (bucket bits only) files under bucket 0 and the
+        // accumulation passes over
         uint32_t key = mag == 0 ? nbuckets : mag - 1;
         uint32_t val = ((uint32_t)w * srs_n + first + i) | (((d < 0) != opposite) ? 0x80000000u : 0u);
         size_t at = (size_t)w * n + i;
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
 }
 
 // ------------------------------------------------------------------------------------------
-// 3. bucket bounds: start[b] = first sorted position with key >= b, b = 0..nbuckets;
-//    start[nbuckets] = number of non-zero digits, start[nbuckets + 1] = total.
+// 3. bucket bounds: start[b] = first sorted position whose bucket (key mod nbuckets) is >= b, b = 0..nbuckets;
+//    start[nbuckets] = start[nbuckets + 1] = total.
 // ------------------------------------------------------------------------------------------
 // One lane per bucket, a binary search each: the cost does not depend on how the keys are spread (a lane
 // per sorted position that fills in the buckets between its key and its neighbour's would loop over all
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_bounds(const uint32_t *__restrict__ key
     if (b > nbuckets) lo = hi;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+        if ((keys[mid] & (nbuckets - 1)) < b) lo = mid + 1; else hi = mid;
     }
     start[b] = lo;
 }
@@ -189,31 +190,35 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     uint32_t k, v, kn, vn;
     pair_at(0, k, v);
     pair_at(1, kn, vn);
-    issue_lines(table, buf, lane, v & 0x7fffffffu);
-    uint32_t cur = k;
+    // (a pair to pass over fetches line 0 instead of its entry's: many of them then cost no memory traffic)
+    issue_lines(table, buf, lane, k < nbuckets ? v & 0x7fffffffu : 0u);
+    const uint32_t bucket_mask = nbuckets - 1;  // a key is a bucket, or nbuckets: a pair of bucket 0 to pass over
+    uint32_t cur = k & bucket_mask;
     uint32_t run_begin = begin;
     G1Xyzz28 acc = xyzz28_identity();
     // The bucket bounds are only meaningful for keys in ascending order; a sort that lost it (see sort.hip on
     // what its ranks rely on) is reported, not trusted: every change of key is checked, and the segment's first
     // key against the one before it.
-    bool out_of_order = live && begin < end && ((begin > 0 && keys[begin - 1] > k) || k >= nbuckets);
+    bool out_of_order = live && begin < end && ((begin > 0 && (keys[begin - 1] & bucket_mask) > cur) || k > nbuckets);
     for (uint32_t it = 0; it < seg_len; it++) {  // the same trip count for every lane of the grid
         const uint32_t p = begin + it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this position's lines have landed
         G1Affine28 pt = read_line(buf, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane holds its line: the buffer is free
-        issue_lines(table, buf, lane, vn & 0x7fffffffu);
+        issue_lines(table, buf, lane, kn < nbuckets ? vn & 0x7fffffffu : 0u);
         uint32_t k2, v2;
         pair_at(it + 2, k2, v2);
         if (p < end) {
-            if (k != cur) {
-                out_of_order = out_of_order || k < cur || k >= nbuckets;
-                if (cur < nbuckets) flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
-                cur = k;
+            const uint32_t kb = k & bucket_mask;
+            out_of_order = out_of_order || k > nbuckets;
+            if (kb != cur) {
+                out_of_order = out_of_order || kb < cur;
+                flush_run(cur, run_begin, p, begin, seg, start, buckets, part, acc);
+                cur = kb;
                 run_begin = p;
                 acc = xyzz28_identity();
             }
-            if (!affine28_is_identity(pt)) {
+            if (k < nbuckets && !affine28_is_identity(pt)) {
                 const bool neg = (v >> 31) != 0;
                 if (xyzz28_is_identity(acc)) {
                     acc.x = pt.x;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         kn = k2;
         vn = v2;
     }
-    if (live && cur < nbuckets) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
+    if (live) flush_run(cur, run_begin, end, begin, seg, start, buckets, part, acc);
     if (out_of_order) __hip_atomic_store(status, kStatusKeysOutOfOrder, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -928,7 +933,8 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     if (!overlap || ctx->npending == kMaxTailSlots) PLONK_TRY(msm_join(ctx));
     const int slot = ctx->npending;
 
-    size_t tmp_bytes = sort_pairs_temp_bytes(total, pl.c);
+    const int key_bits = pl.c - 1;  // the sort orders the pairs by bucket
+    size_t tmp_bytes = sort_pairs_temp_bytes(total, key_bits);
     PLONK_TRY(buf_reserve(ctx, ctx->keys_a, (total + 16) * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->keys_b, (total + 16) * 4));
     PLONK_TRY(buf_reserve(ctx, ctx->vals_a, (total + 16) * 4));
@@ -956,7 +962,7 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
                               (ctx->front_end == kFrontEndScalars || n >= kFrontEndScalarsMin);
     if (ctx->debug_skip_sort) {
         // fault injection: the pairs as the digits come, in the buffers the sort would have left them in
-        const bool odd = (sort_pairs_passes(pl.c) & 1) != 0;
+        const bool odd = (sort_pairs_passes(key_bits) & 1) != 0;
         hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
                            (uint32_t)first, pl.c, pl.nwin, nb, odd ? keys_b : keys_a, odd ? vals_b : vals_a);
         record(ctx, PH_SORT);
@@ -968,9 +974,9 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
         hipLaunchKernelGGL(k_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n, (uint32_t)ctx->srs_n,
                            (uint32_t)first, pl.c, pl.nwin, nb, keys_a, vals_a);
         record(ctx, PH_SORT);
-        PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, pl.c, ctx->sort_tmp.ptr, tmp_bytes));
+        PLONK_TRY(sort_pairs(ctx, keys_a, keys_b, vals_a, vals_b, total, key_bits, ctx->sort_tmp.ptr, tmp_bytes));
     }
-    if ((sort_pairs_passes(pl.c) & 1) == 0) {  // an even number of passes ends in the first pair of buffers
+    if ((sort_pairs_passes(key_bits) & 1) == 0) {  // an even number of passes ends in the first pair of buffers
         keys_b = keys_a;
         vals_b = vals_a;
     }

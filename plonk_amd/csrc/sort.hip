@@ -347,8 +347,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
 // ---- first pass straight from the scalars ------------------------------------------------------------------
 // A block takes kDigitTile consecutive scalars; its digits of window w are sort tile w * (n / kDigitTile) + block
 // of the first pass (any numbering of the tiles will do for the first pass of a sort from the lowest digit up;
-// both kernels use this one).  Pair of scalar i and window w: key = |digit| - 1 (nbuckets for digit 0, which
-// sorts behind every bucket), val = w * srs_n + first + i with the digit's sign in bit 31.
+// both kernels use this one).  Pair of scalar i and window w: key = |digit| - 1, or nbuckets for digit 0 (a pair
+// that contributes nothing: the sort looks at the bucket bits only, so it travels with bucket 0 and the
+// accumulation passes over it), val = w * srs_n + first + i with the digit's sign in bit 31.
 static constexpr int kDigitItems = 8, kDigitWaves = 4, kDigitTile = kDigitWaves * 64 * kDigitItems;
 
 // The next window's pair of a scalar that is shifted down as its windows are used up (the lowest c bits of k
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(kDigitWaves * 64) void k_digits_hist(const Fr *__re
     extern __shared__ uint32_t count[];  // [nwin][bins]
     for (uint32_t j = threadIdx.x; j < (uint32_t)nwin * bins; j += blockDim.x) count[j] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kDigitTile, mask = bins - 1;
+    const uint32_t base = blockIdx.x * kDigitTile, mask = (bins - 1) & (nbuckets - 1);  // bucket bits only
     Fr raw[kDigitItems];
 #pragma unroll
     for (int r = 0; r < kDigitItems; r++) raw[r] = scalars[base + r * (kDigitWaves * 64) + threadIdx.x];
@@ -407,6 +408,8 @@ __global__ __launch_bounds__(kDigitWaves * 64) void k_digits_scatter(const Fr *_
                                                                      uint32_t *__restrict__ vals_out) {
     __shared__ ScatterMem<kDigitWaves, kDigitItems> mem;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, bins = 1u << bits;
+    // rows of `bins` counts, of which a narrow window plan uses the first nbuckets only (bucket bits, see above)
+    const uint32_t digit_bits = bins < nbuckets ? bits : (uint32_t)(c - 1);
     const uint32_t tiles_per_window = n / kDigitTile, block = xcd_contiguous(blockIdx.x, gridDim.x);
     Fr k[kDigitItems];
     uint32_t carry[kDigitItems], index[kDigitItems];
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kDigitWaves * 64) void k_digits_scatter(const Fr *_
         for (int r = 0; r < kDigitItems; r++)
             next_digit_pair(k[r], opposite[r], carry[r], c, nbuckets, (uint32_t)w * srs_n + first + index[r], key[r], val[r]);
         const size_t tile = (size_t)w * tiles_per_window + block;
-        tile_scatter<kDigitWaves, kDigitItems, ATOMIC_RANK>(mem, key, val, kDigitTile, 0u, bits, hist + tile * bins,
+        tile_scatter<kDigitWaves, kDigitItems, ATOMIC_RANK>(mem, key, val, kDigitTile, 0u, digit_bits, hist + tile * bins,
                                                chunk_base + (tile / chunk_tiles) * bins, keys_out, vals_out);
     }
 }
@@ -475,9 +478,10 @@ static int selftest_real_kernels(plonk_hip_ctx *ctx, bool *ok) {
     *ok = false;
     const size_t n = 2 * (size_t)kTile + 1234;           // pairs of the plain sort: two whole tiles and a ragged one
     const size_t ns = 2 * (size_t)kDigitTile;            // scalars of the sort that starts from the scalars
-    const int c = 13, nwin = (255 + c - 1) / c;         // 20 windows of 13 bits: two passes (6 + 7 key bits)
+    const int c = 13, nwin = (255 + c - 1) / c;         // 20 windows of 13 bits: two passes (6 + 6 bucket bits)
     const uint32_t nbuckets = 1u << (c - 1);
     const size_t total = std::max(n, ns * (size_t)nwin), tmp_bytes = sort_pairs_temp_bytes(total, 16);
+    const uint32_t bucket_mask = nbuckets - 1;
     if (!sort_pairs_of_scalars_applies(ns, c, nwin)) return PLONK_HIP_ERR_INVALID_ARG;
     std::vector<uint32_t> keys(n), vals(n), out_k(total), out_v(total);
     std::vector<Fr> scalars(ns);
@@ -527,16 +531,17 @@ static int selftest_real_kernels(plonk_hip_ctx *ctx, bool *ok) {
         e = hipMemcpyAsync(d_sc, scalars.data(), ns * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
             rc = sort_pairs_of_scalars(ctx, d_sc, ns, ns, 0, c, nwin, nbuckets, d[0], d[1], d[2], d[3], d_tmp, tmp_bytes);
-        const int res = (sort_pairs_passes(c) & 1) ? 1 : 0;  // which pair of buffers holds the result
+        const int res = (sort_pairs_passes(c - 1) & 1) ? 1 : 0;  // which pair of buffers holds the result
         if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_k.data(), d[res], pairs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipMemcpyAsync(out_v.data(), d[2 + res], pairs * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && rc == PLONK_HIP_OK) e = hipStreamSynchronize(ctx->stream);
         good = e == hipSuccess && rc == PLONK_HIP_OK;
         for (size_t i = 0; good && i < pairs; i++) {
             const uint32_t entry = out_v[i] & 0x7fffffffu;
+            // ordered by bucket (a digit-0 pair, key nbuckets, counts as bucket 0), entries ascending inside one
+            const uint32_t b = out_k[i] & bucket_mask, before = i ? out_k[i - 1] & bucket_mask : 0u;
             good = out_k[i] <= nbuckets && entry < pairs &&
-                   (i == 0 || out_k[i - 1] < out_k[i] ||
-                    (out_k[i - 1] == out_k[i] && (out_v[i - 1] & 0x7fffffffu) < entry));
+                   (i == 0 || before < b || (before == b && (out_v[i - 1] & 0x7fffffffu) < entry));
         }
     }
     for (int i = 0; i < 4; i++)
@@ -579,7 +584,8 @@ static int fused_first_bits(int end_bit) {
     return std::max(6, end_bit - 8 * later);
 }
 
-bool sort_pairs_of_scalars_applies(size_t n, int end_bit, int nwin) {
+bool sort_pairs_of_scalars_applies(size_t n, int c, int nwin) {
+    const int end_bit = c - 1;  // the bucket bits of a pair's key
     return n > 0 && n % kDigitTile == 0 && end_bit >= 1 && fused_first_bits(end_bit) <= 8 &&
            (size_t)nwin * (1u << fused_first_bits(end_bit)) * 4 <= 48 * 1024 && n * (size_t)nwin < 0xffffffffull;
 }
@@ -634,9 +640,10 @@ int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, siz
                           uint32_t nbuckets, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                           void *temp, size_t temp_bytes) {
     const size_t total = n * (size_t)nwin;
-    if (!sort_pairs_of_scalars_applies(n, c, nwin) || temp_bytes < sort_pairs_temp_bytes(total, c))
+    const int end_bit = c - 1;
+    if (!sort_pairs_of_scalars_applies(n, c, nwin) || temp_bytes < sort_pairs_temp_bytes(total, end_bit))
         return PLONK_HIP_ERR_INVALID_ARG;
-    const int bits = fused_first_bits(c), npasses = sort_pairs_passes(c);
+    const int bits = fused_first_bits(end_bit), npasses = sort_pairs_passes(end_bit);
     const uint32_t bins = 1u << bits, groups = kScanThreads / bins, chunk_tiles = kGroupTiles * groups;
     const uint32_t blocks = (uint32_t)(n / kDigitTile), ntiles = blocks * (uint32_t)nwin, nchunks = cdiv(ntiles, chunk_tiles);
     uint32_t *hist = (uint32_t *)temp, *chunk_total = hist + (size_t)ntiles * bins;
@@ -648,7 +655,7 @@ int sort_pairs_of_scalars(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, siz
                        dim3(kDigitWaves * 64), 0, ctx->stream, d_scalars, (uint32_t)n,
                        (uint32_t)srs_n, (uint32_t)first, c, nwin, nbuckets, (uint32_t)bits, hist, chunk_total, chunk_tiles,
                        keys_b, vals_b);
-    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, total, bits, c, 1, npasses, temp);
+    later_passes(ctx, keys_a, keys_b, vals_a, vals_b, total, std::min(bits, end_bit), end_bit, 1, npasses, temp);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     return PLONK_HIP_OK;
 }
