@@ -52,10 +52,11 @@ int plonk_hip_bench_batch_affine(plonk_hip_ctx *ctx, int accumulators_per_lane, 
  * skip their bucket sort, so the accumulation meets keys that are not in ascending order, which it must report
  * (PLONK_HIP_ERR_INTERNAL at the next wait) instead of returning a wrong point. */
 int plonk_hip_bench_skip_sort(plonk_hip_ctx *ctx, int on);
-/* Measurement override of the bucket accumulation of this context's commitments: seg_len != 0 fixes the number of
- * sorted positions one lane walks (the library otherwise derives it from the size and from the lanes the device
- * keeps resident); 0 restores the library's choice. */
-int plonk_hip_bench_msm_tuning(plonk_hip_ctx *ctx, uint32_t seg_len);
+/* Measurement overrides of the bucket accumulation of this context's commitments: seg_len != 0 fixes the number
+ * of sorted positions one lane walks (the library otherwise derives it from the size and from the lanes the device
+ * keeps resident); pair_loads = 1 makes the lanes fetch their (bucket, entry) pairs one position at a time, 2 eight
+ * at a time through LDS.  0 restores the library's choice of either. */
+int plonk_hip_bench_msm_tuning(plonk_hip_ctx *ctx, uint32_t seg_len, int pair_loads);
 
 #ifdef __cplusplus
 }

@@ -191,10 +191,11 @@ class Backend:
         keys out of order instead of returning a wrong point)."""
         self._check(self._lib.plonk_hip_bench_skip_sort(self._ctx, 1 if on else 0))
 
-    def bench_msm_tuning(self, seg_len=0):
-        """Measurement override of the accumulation's segment length (plonk_hip_bench_msm_tuning); 0 restores the
-        library's own choice."""
-        self._check(self._lib.plonk_hip_bench_msm_tuning(self._ctx, seg_len))
+    def bench_msm_tuning(self, seg_len=0, pair_loads=0):
+        """Measurement overrides of the accumulation (plonk_hip_bench_msm_tuning): segment length, and how the
+        lanes fetch their pairs (1: one position at a time, 2: a group at a time through LDS); 0 restores the
+        library's own choice of either."""
+        self._check(self._lib.plonk_hip_bench_msm_tuning(self._ctx, seg_len, pair_loads))
 
     def bench_gather_rate(self, table_bytes):
         v = ctypes.c_double()

@@ -572,9 +572,10 @@ int plonk_hip_bench_skip_sort(plonk_hip_ctx *ctx, int on) {
     return PLONK_HIP_OK;
 }
 
-int plonk_hip_bench_msm_tuning(plonk_hip_ctx *ctx, uint32_t seg_len) {
-    if (!ctx) return PLONK_HIP_ERR_INVALID_ARG;
+int plonk_hip_bench_msm_tuning(plonk_hip_ctx *ctx, uint32_t seg_len, int pair_loads) {
+    if (!ctx || pair_loads < 0 || pair_loads > 2) return PLONK_HIP_ERR_INVALID_ARG;
     ctx->tune_seg_len = seg_len;
+    ctx->tune_pair_loads = pair_loads;
     return PLONK_HIP_OK;
 }
 

@@ -71,6 +71,7 @@ struct plonk_hip_ctx {
     bool lds_rank_in_lane_order = false;
     // measurement override (plonk_hip_bench_msm_tuning): segment length of the accumulation (0: the library's choice)
     uint32_t tune_seg_len = 0;
+    int tune_pair_loads = 0;  // 0: the library's choice, 1: one position at a time, 2: a group at a time through LDS
     bool debug_skip_sort = false;  // fault injection (plonk_hip_bench_skip_sort): hand the accumulation unsorted pairs
 
     // SRS: `table` holds plan.nwin levels of srs_n affine points in the 28-bit limb form

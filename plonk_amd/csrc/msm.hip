@@ -154,8 +154,17 @@ __device__ __forceinline__ G1Affine28 read_line(const uint4 *buf, uint32_t lane)
 // Two waves per SIMD: the whole addition then lives in registers.  A third wave (168 registers)
 // spills about 60 bytes per lane and iteration, which showed up as 13 GB of write traffic per
 // 2^24-point launch and cost more than the extra wave hid.
-// A lane fetches its (bucket, entry) pairs one position at a time, two positions ahead of the addition.  Bringing
-// them in sixteen at a time through LDS measured 2 to 3 % slower from 2^19 points up and the same below.
+// LDS_PAIRS (what the library uses): a lane's (bucket, entry) pairs come in kGroup positions at a time (32 bytes of
+// each list, on 16-byte boundaries) by direct global-to-LDS loads into a buffer of the wave in which every lane has
+// a place of its own; the loop reads one pair per iteration from there.  Without it (kept for measurements) a
+// lane fetches its pairs one position at a time, two positions ahead of the addition: the lanes of a wave then
+// walk 64 different 128-byte lines of each list for 32 iterations, and the lines are fetched from memory about
+// thirteen times over (50 GB instead of 30 GB per 2^24-point launch) for the same speed.
+// The block's LDS stays at 24 KiB: from 32 KiB per block of two waves on, the kernel measured 5 % slower whatever
+// its loads looked like (which is what made groups of sixteen positions look slower than single loads).
+static constexpr uint32_t kGroup = 8;  // positions per group (a multiple of four)
+
+template <bool LDS_PAIRS>
 __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals,
                                                        const uint32_t *__restrict__ start, uint32_t nbuckets,
@@ -163,8 +172,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
                                                        G1Xyzz28 *__restrict__ buckets,
                                                        G1Xyzz28 *__restrict__ part, uint32_t *status) {
     __shared__ uint4 line_buf[kBlock / 64][64 * 8];                           // 8 KiB per wave
+    __shared__ uint4 pair_buf[LDS_PAIRS ? kBlock / 64 : 1][2][kGroup / 4][64];  // 4 KiB per wave
     const uint32_t lane = threadIdx.x & 63;
     uint4 *buf = line_buf[threadIdx.x >> 6];
+    uint4(*pbuf)[kGroup / 4][64] = pair_buf[LDS_PAIRS ? threadIdx.x >> 6 : 0];
     const size_t seg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nvalid = start[nbuckets];
     const size_t begin64 = seg * seg_len;
@@ -175,8 +186,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
     const size_t end64 = begin64 + seg_len;
     const uint32_t end = live ? (end64 < nvalid ? (uint32_t)end64 : nvalid) : 0u;
 
-    // pair at position begin + o (zeros behind the segment's end)
-    auto pair_at = [&](uint32_t o, uint32_t &key, uint32_t &val) {
+    // pair at position begin + o (zeros behind the segment's end), straight from the lists
+    auto pair_direct = [&](uint32_t o, uint32_t &key, uint32_t &val) {
         key = 0;
         val = 0;
         if (begin + o < end) {
@@ -184,12 +195,40 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
             val = vals[begin + o];
         }
     };
+    // Group g of a lane: the kGroup positions from base + kGroup g on, base = begin rounded down to a multiple of
+    // four (the lists have sixteen positions of slack behind their end).  The wave's buffer holds one group per lane.
+    const uint32_t base = begin & ~3u;
+    auto group_issue = [&](uint32_t g) {
+        const uint32_t first = base + kGroup * g;
+        if (first < end) {
+#pragma unroll
+            for (uint32_t q = 0; q < kGroup / 4; q++) {
+                // destination: wave-uniform base; the hardware adds lane * 16
+                __builtin_amdgcn_global_load_lds((global_void_t *)(keys + first + 4 * q), (lds_void_t *)&pbuf[0][q][0], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_void_t *)(vals + first + 4 * q), (lds_void_t *)&pbuf[1][q][0], 16, 0, 0);
+            }
+        }
+    };
+    auto pair_at = [&](uint32_t o, uint32_t &key, uint32_t &val) {
+        if (!LDS_PAIRS) {
+            pair_direct(o, key, val);
+            return;
+        }
+        key = 0;
+        val = 0;
+        if (begin + o < end) {
+            const uint32_t j = begin + o - base;
+            key = reinterpret_cast<const uint32_t *>(&pbuf[0][(j >> 2) % (kGroup / 4)][lane])[j & 3];
+            val = reinterpret_cast<const uint32_t *>(&pbuf[1][(j >> 2) % (kGroup / 4)][lane])[j & 3];
+        }
+    };
 
     // (bucket, entry) of the current position and of the next one; the line of the current
     // position is always on its way to (or in) the wave's buffer
     uint32_t k, v, kn, vn;
-    pair_at(0, k, v);
-    pair_at(1, kn, vn);
+    pair_direct(0, k, v);
+    pair_direct(1, kn, vn);
+    if (LDS_PAIRS) group_issue((begin + 2 - base) / kGroup);  // the group of the first position the loop reads
     // (a pair to pass over fetches line 0 instead of its entry's: many of them then cost no memory traffic)
     issue_lines(table, buf, lane, k < nbuckets ? v & 0x7fffffffu : 0u);
     const uint32_t bucket_mask = nbuckets - 1;  // a key is a bucket, or nbuckets: a pair of bucket 0 to pass over
@@ -208,6 +247,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_accumulate(const uint32_t *__rest
         issue_lines(table, buf, lane, kn < nbuckets ? vn & 0x7fffffffu : 0u);
         uint32_t k2, v2;
         pair_at(it + 2, k2, v2);
+        if (LDS_PAIRS) {
+            // the next position opens a new group: this lane's group is used up, fetch the next one into its place
+            // (it lands with the wait at the top of the loop)
+            const uint32_t jn = begin + it + 3 - base;
+            if (jn % kGroup == 0 && it + 3 < seg_len) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                group_issue(jn / kGroup);
+            }
+        }
         if (p < end) {
             const uint32_t kb = k & bucket_mask;
             out_of_order = out_of_order || k > nbuckets;
@@ -1014,8 +1062,9 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, cap, chunk_parts, queue, max_joins,
                        max_items, max_slots, ctx->status_dev);
     record(ctx, PH_ACCUM);
-    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st, keys_b, vals_b, start, nb, seg_len,
-                       table, buckets, part, ctx->status_dev);
+    const bool lds_pairs = ctx->tune_pair_loads != 1;
+    hipLaunchKernelGGL(lds_pairs ? k_accumulate<true> : k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st,
+                       keys_b, vals_b, start, nb, seg_len, table, buckets, part, ctx->status_dev);
     PLONK_HIP_TRY(ctx, hipGetLastError());
     TailDesc &d = ctx->pending[slot];
     d.start = start;

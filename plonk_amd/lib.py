@@ -87,7 +87,7 @@ SIGNATURES = {
     "plonk_hip_bench_gather_rate": (ctypes.c_int, [c_ctx, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]),
     "plonk_hip_bench_sort_rank_mode": (ctypes.c_int, [c_ctx]),
     "plonk_hip_bench_skip_sort": (ctypes.c_int, [c_ctx, ctypes.c_int]),
-    "plonk_hip_bench_msm_tuning": (ctypes.c_int, [c_ctx, ctypes.c_uint32]),
+    "plonk_hip_bench_msm_tuning": (ctypes.c_int, [c_ctx, ctypes.c_uint32, ctypes.c_int]),
     "plonk_hip_bench_batch_affine": (
         ctypes.c_int, [c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_u64p]),
     "plonk_hip_fr_ntt_mixed": (ctypes.c_int, [c_ctx, c_u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),

@@ -335,7 +335,8 @@ def test_commit_2_24_points_known_answer(backend):
     backend.free(d_out)
 
 
-@pytest.mark.parametrize("log_n,ranks,window_bits", [(18, 4, 0), (14, 2, 9), (12, 8, 6)])
+# (13, 2, 20): slices of 2^18 buckets, which the reduction sums in two levels
+@pytest.mark.parametrize("log_n,ranks,window_bits", [(18, 4, 0), (14, 2, 9), (12, 8, 6), (13, 2, 20)])
 def test_bucket_partial_exchange(backend, log_n, ranks, window_bits):
     """The multi-GPU exchange of bucket partials, with the ranks played one after the other on this
     GPU: every rank stops after its bucket sums, slice g of every rank's array goes to rank g, the
