@@ -1062,7 +1062,8 @@ int msm_run_dev(plonk_hip_ctx *ctx, const Fr *d_scalars, size_t n, G1Jac *d_out,
     hipLaunchKernelGGL(k_classify, dim3(cdiv(nb, 256)), dim3(256), 0, st, start, nb, seg_len, cap, chunk_parts, queue, max_joins,
                        max_items, max_slots, ctx->status_dev);
     record(ctx, PH_ACCUM);
-    const bool lds_pairs = ctx->tune_pair_loads != 1;
+    // segments shorter than a group: nothing to bring in ahead
+    const bool lds_pairs = ctx->tune_pair_loads ? ctx->tune_pair_loads == 2 : seg_len >= kGroup;
     hipLaunchKernelGGL(lds_pairs ? k_accumulate<true> : k_accumulate<false>, dim3(cdiv(nseg, kBlock)), dim3(kBlock), 0, st,
                        keys_b, vals_b, start, nb, seg_len, table, buckets, part, ctx->status_dev);
     PLONK_HIP_TRY(ctx, hipGetLastError());
