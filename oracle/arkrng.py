@@ -80,6 +80,27 @@ class StdRng:
         return lo | (self.next_u32() << 32)
 
 
+def gen_range_u32(rng, bound):
+    """rand 0.8 `rng.gen_range(0..bound)` for a u32 bound (UniformInt::sample_single): a 32-bit draw v, the
+    64-bit product v * bound, accepted when its low word lies in the zone (bound << leading_zeros(bound)) - 1;
+    the result is the high word."""
+    zone = ((bound << (32 - bound.bit_length())) - 1) & MASK32
+    while True:
+        m = rng.next_u32() * bound
+        if (m & MASK32) <= zone:
+            return m >> 32
+
+
+def shuffle(rng, items):
+    """rand 0.8 `SliceRandom::shuffle` (in place): for i = len - 1 down to 1, swap(i, gen_range(0..i + 1)).
+    UNPINNED: restated from the published algorithm; nothing the reference holds depends on which permutation
+    comes out (plonk/tests/protocols_tests.rs:665, 794 only need SOME permutation), so no fixture can confirm the
+    draw-by-draw agreement of what follows a shuffle."""
+    for i in range(len(items) - 1, 0, -1):
+        j = gen_range_u32(rng, i + 1)
+        items[i], items[j] = items[j], items[i]
+
+
 def test_rng():
     """`ark_std::test_rng()`: a fresh generator from the fixed seed on every call."""
     return StdRng()

@@ -692,6 +692,33 @@ def verify_sum_check(kzg_verify, w, k, com_f, r, p):
             and kzg_verify(com_f, r * w % R, p["f_w_r"], p["proof_f_w_r"]))
 
 
+def verify_prescribed_permutation_check(kzg_verify, w, k, com_f, com_g, com_W, r, s, rp, p):
+    """common/protocols.rs:690-719."""
+    z = (pow(rp, k, R) - 1) % R
+    wrp = rp * w % R
+    lhs = (p["t_w_rp"] * (r - s * w * rp - p["g_w_rp"]) - p["t_rp"] * (r - s * p["W_w_rp"] - p["f_w_rp"])) % R
+    return (p["t_w_k_minus_1"] == 1 and lhs == p["q_rp"] * z % R
+            and kzg_verify(p["com_t"], pow(w, k - 1, R), p["t_w_k_minus_1"], p["proof_t_w_k_minus_1"])
+            and kzg_verify(p["com_t"], rp, p["t_rp"], p["proof_t_rp"])
+            and kzg_verify(p["com_t"], wrp, p["t_w_rp"], p["proof_t_w_rp"])
+            and kzg_verify(p["com_q"], rp, p["q_rp"], p["proof_q_rp"])
+            and kzg_verify(com_f, wrp, p["f_w_rp"], p["proof_f_w_rp"])
+            and kzg_verify(com_g, wrp, p["g_w_rp"], p["proof_g_w_rp"])
+            and kzg_verify(com_W, wrp, p["W_w_rp"], p["proof_W_w_rp"]))
+
+
+def verify_T_S_zero_test(kzg_verify, w, Omega_gates, com_T, com_S, r, p):
+    """common/protocols.rs:789-809."""
+    z_r = poly_eval(construct_vanishing_polynomial_from_roots(Omega_gates), r)
+    lhs = (p["S_r"] * (p["T_r"] + p["T_w_r"]) + (1 - p["S_r"]) * p["T_r"] * p["T_w_r"] - p["T_w2_r"]) % R
+    return (lhs == p["q_r"] * z_r % R
+            and kzg_verify(com_T, r, p["T_r"], p["proof_T_r"])
+            and kzg_verify(com_T, w * r % R, p["T_w_r"], p["proof_T_w_r"])
+            and kzg_verify(com_T, w * w * r % R, p["T_w2_r"], p["proof_T_w2_r"])
+            and kzg_verify(com_S, r, p["S_r"], p["proof_S_r"])
+            and kzg_verify(p["com_q"], r, p["q_r"], p["proof_q_r"]))
+
+
 # ---------------------------------------------------------------------------
 # setup_proving_key / setup_verification_key / prover (the example circuit)
 # ---------------------------------------------------------------------------

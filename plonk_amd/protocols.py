@@ -1,4 +1,4 @@
-"""Prover halves of the reference's poly-IOP gadgets (plonk/src/common/protocols.rs) on limb arrays, every
+"""Both halves of the reference's poly-IOP gadgets (plonk/src/common/protocols.rs) on limb arrays, every
 polynomial operation and every group operation done by the HIP library through `Backend`.
 
 Same names and argument order as the reference; `gp: &GlobalParameters` becomes the `Backend` whose context
@@ -102,6 +102,36 @@ def compute_t_and_t1_sum_check(be, Omega, f):
     return t, t1
 
 
+def compute_t_and_t1_prescribed_permutation_check(be, Omega, f, g, W, r, s):
+    """protocols.rs:559-638: t(Omega[i]) = prod_{j<=i} (r - s W(w^j) - f(w^j)) / (r - s w^j - g(w^j));
+    t1 = t(wX)(r - s w X - g(wX)) - t (r - s W(wX) - f(wX)).  A zero denominator on Omega raises ReferencePanic
+    (`inverse().unwrap()`, :583)."""
+    w = Omega[1]
+    minus_s = _m((R_MOD - _i(s)) % R_MOD)
+    minus_1 = _m(R_MOD - 1)
+    num = be.fr_linear_combination(_evaluate_over(be, W, Omega), _evaluate_over(be, f, Omega), minus_s, minus_1, r,
+                                   broadcast=True)
+    den = be.fr_linear_combination(Omega, _evaluate_over(be, g, Omega), minus_s, minus_1, r, broadcast=True)
+    t = _interpolate_t(be, Omega, be.fr_ratio_prefix_product(num, den), f)
+    r_s_w_x = np.stack([np.asarray(r, dtype=np.uint64).reshape(4), _fr_mul(minus_s, w)])
+    a = trim(be.fr_linear_combination(r_s_w_x, _shift(be, g, w), _m(1), minus_1, _m(0)))
+    b = trim(be.fr_linear_combination(_shift(be, W, w), _shift(be, f, w), minus_s, minus_1, r))
+    t1 = _lin(be, _mul(be, _shift(be, t, w), a), _mul(be, t, b), 1, R_MOD - 1)
+    return t, t1
+
+
+def compute_t1_T_S_zero_test(be, w, T, S):
+    """protocols.rs:722-750: t1 = S (T + T(wY)) + (1 - S) T T(wY) - T(w^2 Y)."""
+    T_w = _shift(be, T, w)
+    T_w2 = _shift(be, T, _fr_mul(w, w))
+    if S.shape[0] < 2:
+        raise RuntimeError("compose_polynomials panics in the reference for len(S) < 2")
+    one_minus_S = trim(be.fr_linear_combination(S, S[:0], _m(R_MOD - 1), _m(0), _m(1)))
+    first = _mul(be, S, _lin(be, T, T_w, 1, 1))
+    second = _mul(be, _mul(be, one_minus_S, T), T_w)
+    return _lin(be, _lin(be, first, second, 1, 1), T_w2, 1, R_MOD - 1)
+
+
 def _open(be, f, points):
     vs, proofs = be.kzg_evaluate_many(f, np.stack(points))
     return [(vs[i], proofs[i]) for i in range(len(points))]
@@ -156,6 +186,29 @@ def prove_product_check_rational_functions(be, w, k, t, q, f, g, r):
     p = prove_product_check(be, w, k, t, q, f, r)
     (p["g_w_r"], p["proof_g_w_r"]), = _open(be, g, [_fr_mul(r, w)])
     return p
+
+
+def prove_prescribed_permutation_check(be, w, k, t, q, f, g, W, rp):
+    """protocols.rs:641-687."""
+    c = _prove_t_q(be, w, k, t, q, rp)
+    wrp = _fr_mul(rp, w)
+    p = dict(com_t=c["com_t"], com_q=c["com_q"], t_w_k_minus_1=c["t_w_k_minus_1"],
+             proof_t_w_k_minus_1=c["proof_t_w_k_minus_1"], t_rp=c["t_r"], proof_t_rp=c["proof_t_r"],
+             t_w_rp=c["t_w_r"], proof_t_w_rp=c["proof_t_w_r"], q_rp=c["q_r"], proof_q_rp=c["proof_q_r"])
+    for name, poly in (("f", f), ("g", g), ("W", W)):
+        (p[name + "_w_rp"], p["proof_" + name + "_w_rp"]), = _open(be, poly, [wrp])
+    return p
+
+
+def prove_T_S_zero_test(be, w, q, T, S, r):
+    """protocols.rs:753-786."""
+    com_q = be.kzg_commit(q)
+    wr = _fr_mul(w, r)
+    (T_r, p_T_r), (T_w_r, p_T_w_r), (T_w2_r, p_T_w2_r) = _open(be, T, [r, wr, _fr_mul(w, wr)])
+    (S_r, p_S_r), = _open(be, S, [r])
+    (q_r, p_q_r), = _open(be, q, [r])
+    return dict(com_q=com_q, T_r=T_r, proof_T_r=p_T_r, T_w_r=T_w_r, proof_T_w_r=p_T_w_r, T_w2_r=T_w2_r,
+                proof_T_w2_r=p_T_w2_r, S_r=S_r, proof_S_r=p_S_r, q_r=q_r, proof_q_r=p_q_r)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -218,3 +271,33 @@ def verify_sum_check(tau_g2, w, k, com_f, r, p):
     """protocols.rs:535-556."""
     return _verify_t_q(tau_g2, w, k, r, p, 0, _i(p["t_w_r"]) - (_i(p["t_r"]) + _i(p["f_w_r"])),
                        [(com_f, "f_w_r", "proof_f_w_r")])
+
+
+def verify_prescribed_permutation_check(tau_g2, w, k, com_f, com_g, com_W, r, s, rp, p):
+    """protocols.rs:690-719."""
+    z = (pow(_i(rp), k, R_MOD) - 1) % R_MOD
+    lhs = (_i(p["t_w_rp"]) * (_i(r) - _i(s) * _i(w) * _i(rp) - _i(p["g_w_rp"]))
+           - _i(p["t_rp"]) * (_i(r) - _i(s) * _i(p["W_w_rp"]) - _i(p["f_w_rp"]))) % R_MOD
+    if _i(p["t_w_k_minus_1"]) != 1 or lhs != _i(p["q_rp"]) * z % R_MOD:
+        return False
+    wrp = _fr_mul(rp, w)
+    return _pairings(tau_g2, [(p["com_t"], _fr_pow(w, k - 1), p["t_w_k_minus_1"], p["proof_t_w_k_minus_1"]),
+                              (p["com_t"], rp, p["t_rp"], p["proof_t_rp"]),
+                              (p["com_t"], wrp, p["t_w_rp"], p["proof_t_w_rp"]),
+                              (p["com_q"], rp, p["q_rp"], p["proof_q_rp"]),
+                              (com_f, wrp, p["f_w_rp"], p["proof_f_w_rp"]),
+                              (com_g, wrp, p["g_w_rp"], p["proof_g_w_rp"]),
+                              (com_W, wrp, p["W_w_rp"], p["proof_W_w_rp"])])
+
+
+def verify_T_S_zero_test(be, tau_g2, w, Omega_gates, com_T, com_S, r, p):
+    """protocols.rs:789-809."""
+    z = _i(be.fr_eval(be.construct_vanishing_polynomial_from_roots(Omega_gates), r))
+    S_r, T_r, T_w_r = _i(p["S_r"]), _i(p["T_r"]), _i(p["T_w_r"])
+    lhs = (S_r * (T_r + T_w_r) + (1 - S_r) * T_r * T_w_r - _i(p["T_w2_r"])) % R_MOD
+    if lhs != _i(p["q_r"]) * z % R_MOD:
+        return False
+    wr = _fr_mul(w, r)
+    return _pairings(tau_g2, [(com_T, r, p["T_r"], p["proof_T_r"]), (com_T, wr, p["T_w_r"], p["proof_T_w_r"]),
+                              (com_T, _fr_mul(w, wr), p["T_w2_r"], p["proof_T_w2_r"]),
+                              (com_S, r, p["S_r"], p["proof_S_r"]), (p["com_q"], r, p["q_r"], p["proof_q_r"])])

@@ -99,6 +99,63 @@ def test_equality_and_zero_tests(success):
     assert o.verify_zero_on_roots_test(check, c["roots"], o.kzg_commit(gp, c["f"]), c["r"], p) == success
 
 
+@pytest.mark.parametrize("success", [True, False])
+def test_permutation_prescribed_permutation_and_T_S_gadgets(success):
+    """protocols_tests.rs:646-1149 on the oracle: permutation check (through the product check of rational
+    functions), prescribed permutation check, T_S zero test; the degrees the reference asserts (:684-685, :829-831,
+    :1037, :1058) and its verdicts."""
+    # :646-776
+    c = flows.permutation_check(success)
+    gp, tau = a.kzg_setup(c["degree"])
+    check = o.kzg_verify_with_tau(tau)
+    Omega, f, g, r, w = c["Omega"], c["f"], c["g"], c["r"], c["Omega"][1]
+    assert o.poly_degree(f) == 10 and o.poly_degree(g) == 10
+    t, t1 = o.compute_t_and_t1_product_check_rational_functions(Omega, f, g)
+    q = o.compute_q_zero_test(flows.K, t1)
+    assert (o.poly_mul(q, o.construct_vanishing_polynomial(flows.K)) == o.poly_trim(t1)) == success
+    p = o.prove_product_check_rational_functions(gp, w, flows.K, t, q, f, g, r)
+    assert o.verify_product_check_rational_functions(check, w, flows.K, o.kzg_commit(gp, f), o.kzg_commit(gp, g), r,
+                                                     p) == success
+    # :778-943
+    c = flows.prescribed_permutation_check(success)
+    f, g, W = c["f"], c["g"], c["W"]
+    assert [o.poly_degree(x) for x in (f, g, W)] == [10, 10, 10]
+    assert all(o.poly_eval(f, x) == o.poly_eval(g, o.poly_eval(W, x)) for x in Omega) == success
+    t, t1 = o.compute_t_and_t1_prescribed_permutation_check(Omega, f, g, W, c["r"], c["s"])
+    q = o.compute_q_zero_test(flows.K, t1)
+    assert (o.poly_mul(q, o.construct_vanishing_polynomial(flows.K)) == o.poly_trim(t1)) == success
+    p = o.prove_prescribed_permutation_check(gp, w, flows.K, t, q, f, g, W, c["rp"])
+    assert o.verify_prescribed_permutation_check(check, w, flows.K, o.kzg_commit(gp, f), o.kzg_commit(gp, g),
+                                                 o.kzg_commit(gp, W), c["r"], c["s"], c["rp"], p) == success
+    # :945-1149
+    c = flows.t_s_zero_test(success)
+    gp, tau = a.kzg_setup(c["degree"])
+    check = o.kzg_verify_with_tau(tau)
+    T, S, gates, w = c["T"], c["S"], c["Omega_gates"], c["Omega"][1]
+    assert o.poly_degree(T) == 11 and o.poly_degree(S) == 2
+    t1 = o.compute_t1_T_S_zero_test(w, T, S)
+    assert o.poly_degree(t1) == 24
+    assert all((o.poly_eval(t1, y) == 0) == success for y in gates)
+    q = o.compute_q_zero_test_from_roots(gates, t1)
+    assert o.poly_degree(q) == 21
+    z = o.construct_vanishing_polynomial_from_roots(gates)
+    assert (o.poly_mul(q, z) == o.poly_trim(t1)) == success
+    p = o.prove_T_S_zero_test(gp, w, q, T, S, c["r"])
+    assert o.verify_T_S_zero_test(check, w, gates, o.kzg_commit(gp, T), o.kzg_commit(gp, S), c["r"], p) == success
+
+
+def test_shuffle_is_a_permutation_drawn_in_32_bit_words():
+    rng, ref = a.test_rng(), a.test_rng()
+    items = list(range(8))
+    a.shuffle(rng, items)
+    assert sorted(items) == list(range(8)) and items != list(range(8))
+    # seven swaps, each one accepted 32-bit draw after any rejected ones (the zone test accepts at least half)
+    words = [ref.next_u32() for _ in range(64)]
+    follow = rng.next_u32()
+    assert any(follow == words[n] for n in range(7, 64))
+    assert a.gen_range_u32(a.test_rng(), 1) == 0
+
+
 def test_one_pairing_check_agrees_with_the_trapdoor_check():
     from oracle import pairing
     c = flows.sum_check(True)
