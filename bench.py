@@ -808,9 +808,9 @@ def main():
             if isinstance(shared_prover, tuple):
                 extras["prove_latency_s"] = round(shared_prover[0], 3)
                 extras["prove_latency_note"] = (
-                    "full proof of a synthetic circuit of 2^%d - 1 gates; every rank builds the polynomials, the 18 "
-                    "independent commitments and openings are dealt out by size to the %d GPUs (sharing by polynomial) and "
-                    "gathered; each rank's share checked against the test SRS trapdoor, verifier's field equations: %s"
+                    "full proof of a synthetic circuit of 2^%d - 1 gates; the 18 independent commitments and openings are "
+                    "dealt out by size to the %d GPUs (sharing by polynomial), every rank builds only the polynomials its "
+                    "own tasks need, and the results are gathered; each rank's share checked against the test SRS trapdoor, verifier's field equations: %s"
                     % (args.prover_log_gates, world, shared_prover[1]))
             else:
                 extras["prove_latency_s"] = None
