@@ -1,6 +1,6 @@
 """Random commitments against the known answer [f(tau)]G (development aid; the answer needs no oracle: f(tau) by
 the library's evaluation kernel, then a one-coefficient commitment, compared as compressed encodings).
-usage: python scripts/fuzz_msm.py SECONDS [SEED [MULTIPLE]]
+usage: python scripts/fuzz_msm.py SECONDS [SEED [MULTIPLE [MAX_LOG]]]
 Sizes 1 .. 2^18 (log-uniform), window widths 0 (automatic) or 2 .. 20, scalars uniform or from a small set of
 special values (0, 1, r - 1, (r - 1) / 2, (r + 1) / 2, 2^254, repeated), single commitments, batches, and openings
 checked by the pairing equation.  With MULTIPLE (e.g. 2048) the lengths are whole multiples of it where the SRS is
@@ -19,12 +19,13 @@ from plonk_amd.prover import R_MOD, to_mont
 seconds = float(sys.argv[1])
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 multiple = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+max_log = int(sys.argv[4]) if len(sys.argv) > 4 else 18  # SRS sizes up to 2^MAX_LOG (log-uniform)
 special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, (R_MOD + 1) // 2, 1 << 254, (1 << 254) - 1, (1 << 255) % R_MOD]
 t0 = last = time.perf_counter()
 cases = failures = 0
 while time.perf_counter() - t0 < seconds:
-    n = max(1, int(2 ** rnd.uniform(0, 18)))
-    c = rnd.choice([0, 0, 0] + list(range(2, 21)))
+    n = max(1, int(2 ** rnd.uniform(0, max_log)))
+    c = rnd.choice([0, 0, 0] + list(range(2, 21))) if n <= 1 << 18 else rnd.choice([0, 0] + list(range(15, 24)))
     be = plonk_amd.Backend(0, window_bits=c)
     tau = to_mont([rnd.randrange(1, R_MOD)])[0]
     be.kzg_setup(tau, n - 1, want_points=False)
