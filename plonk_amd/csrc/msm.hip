@@ -443,15 +443,16 @@ __device__ __forceinline__ bool coop_is_identity(const CoopMem &m, int base, uin
     return z == 0;
 }
 
-// A[s] += (b_self ? A : B)[s + boff] for the slots s < nact (s + boff < 64).  Called by all 256
+// A[s] += (b_self ? A : B)[s + boff] for the slots s with (s & seg_mask) < nact (s + boff < 64; seg_mask = 63: the
+// slots s < nact; seg_mask = 31: the same in each half of the slots).  Called by all 256
 // threads of the block after a barrier that made the operands visible; ends with a barrier.
 // Whether the staged loop (which contains barriers) runs is decided by a block-wide vote that is itself
 // a barrier (__syncthreads_or): all four waves take the same branch by construction, whatever each of
 // them read, and nothing below writes a point before every wave has taken its decisions.
-__device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact) {
+__device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact, uint32_t seg_mask = 63u) {
     const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
     CoopSlot c{&m, s, (s + boff) & 63u, b_self ? kCoopA : kCoopB};
-    const bool act = s < nact;
+    const bool act = (s & seg_mask) < nact;
     const bool ida = act && coop_is_identity(m, kCoopA, s);
     const bool idb = !act || coop_is_identity(m, c.bbase, c.sb);
     const bool live = act && !ida && !idb;
@@ -512,6 +513,30 @@ __device__ __forceinline__ G1Xyzz28 block_sum_coop(uint32_t cnt, CoopMem &m, At 
     G1Xyzz28 r = coop_load(m, kCoopA, 0);
     __syncthreads();  // the caller may start the next sum
     return r;
+}
+
+// Two sums of exactly 256 points each by one block of 256 threads; the first is valid in slot 0, the second in
+// slot 32 of the A values (coop_load).  With more sums than compute units a block per sum runs in two rounds of
+// nine additions, six of them on 32, 16, ... 1 of the 64 slots; two sums side by side share the slots instead:
+// slots 0-31 belong to the first sum, 32-63 to the second, every thread brings in two points of its half's sum
+// (eight loads of 64 slots: seven additions), and five halvings work on both halves at once: twelve additions
+// per pair of sums instead of eighteen.
+template <class At0, class At1>
+__device__ __forceinline__ void block_sum_coop_pair(CoopMem &m, At0 at0, At1 at1) {
+    const uint32_t t = threadIdx.x, w = t >> 6, s = t & 63, e = s & 31;
+    // point (4 r + w) * 32 + e of this half's sum goes in at step 4 r + w: a thread's second point is fetched
+    // while the other waves take their turns
+    auto fetch = [&](uint32_t r) { return s < 32 ? *at0((4 * r + w) * 32 + e) : *at1((4 * r + w) * 32 + e); };
+    G1Xyzz28 mine = fetch(0);
+    for (uint32_t step = 0; step < 8; step++) {
+        if (w == (step & 3)) {
+            coop_store(m, step == 0 ? kCoopA : kCoopB, s, mine);
+            if (step < 4) mine = fetch(1);
+        }
+        __syncthreads();
+        if (step > 0) coop_add(m, false, 0, 64);
+    }
+    for (uint32_t off = 16; off > 0; off >>= 1) coop_add(m, true, off, off, 31u);
 }
 
 // Buckets cut into more partials than a lane group handles go to the block path, in chunks of chunk_parts
@@ -738,6 +763,26 @@ __global__ __launch_bounds__(kTreeBlock) void k_row_col_sums_of_partials(TailBat
     if (threadIdx.x == 0) (row ? R[i] : C[i - H]) = acc;
 }
 
+// H = L = 256: two sums per block (rows 2i and 2i + 1, or columns 2i and 2i + 1)
+__global__ __launch_bounds__(256) void k_row_col_sums_coop_pair(TailBatch tb) {
+    __shared__ CoopMem mem;
+    constexpr uint32_t H = 256, L = 256;
+    const TailDesc &d = tb.d[blockIdx.y];
+    if (!d.out) return;
+    const G1Xyzz28 *__restrict__ B = (const G1Xyzz28 *)d.buckets;
+    G1Xyzz28 *__restrict__ R = (G1Xyzz28 *)d.red, *__restrict__ C = R + H;
+    const uint32_t i = 2 * blockIdx.x;
+    const bool row = i < H;
+    const G1Xyzz28 *base = row ? B + (size_t)i * L : B + (i - H);
+    const size_t stride = row ? 1 : L, next = row ? L : 1;
+    block_sum_coop_pair(mem, [&](uint32_t j) { return base + (size_t)j * stride; },
+                        [&](uint32_t j) { return base + next + (size_t)j * stride; });
+    if (threadIdx.x == 0) {
+        (row ? R[i] : C[i - H]) = coop_load(mem, kCoopA, 0);
+        (row ? R[i + 1] : C[i + 1 - H]) = coop_load(mem, kCoopA, 32);
+    }
+}
+
 // block i < lbits: T_i over C; lbits <= i < lbits + hbits: T_i over R; block lbits + hbits: T_all
 __global__ __launch_bounds__(256) void k_bit_sums(TailBatch tb, uint32_t hbits, uint32_t lbits) {
     __shared__ CoopMem mem;
@@ -904,6 +949,8 @@ static int reduce_buckets(plonk_hip_ctx *ctx, const TailBatch &tb, uint32_t coun
         const uint32_t lanes = 2 * ((1u << sbits) / m);
         hipLaunchKernelGGL(k_row_col_partials, dim3(lanes / 128, count), dim3(128), 0, st, tb, H, L, m);
         hipLaunchKernelGGL(k_row_col_sums_of_partials, dim3(sums, count), dim3(64), 0, st, tb, H, L, m);
+    } else if (H == 256 && L == 256 && count == 1) {  // more sums than compute units: two per block
+        hipLaunchKernelGGL(k_row_col_sums_coop_pair, dim3(sums / 2, count), dim3(256), 0, st, tb);
     } else if (all_sums <= 512) {  // (at 512 sums: 0.60 against 0.62 ms for the whole reduction of 2^16 buckets)
         hipLaunchKernelGGL(k_row_col_sums_coop, dim3(sums, count), dim3(256), 0, st, tb, H, L);
     } else {
