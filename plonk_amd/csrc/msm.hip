@@ -449,7 +449,9 @@ __device__ __forceinline__ bool coop_is_identity(const CoopMem &m, int base, uin
 // Whether the staged loop (which contains barriers) runs is decided by a block-wide vote that is itself
 // a barrier (__syncthreads_or): all four waves take the same branch by construction, whatever each of
 // them read, and nothing below writes a point before every wave has taken its decisions.
-__device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact, uint32_t seg_mask = 63u) {
+// Inlined, and every kernel calls it from ONE place (a loop over its steps): as a function of its own it saved and
+// restored about a hundred registers per call through scratch memory, 7 000 of the 22 000 cycles of a call.
+__device__ __forceinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, uint32_t nact, uint32_t seg_mask = 63u) {
     const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
     CoopSlot c{&m, s, (s + boff) & 63u, b_self ? kCoopA : kCoopB};
     const bool act = (s & seg_mask) < nact;
@@ -476,7 +478,7 @@ __device__ __noinline__ void coop_add(CoopMem &m, bool b_self, uint32_t boff, ui
 }
 
 // A[s] <- 2 A[s] in the slots that `want` it; same calling rules as coop_add.
-__device__ __noinline__ void coop_dbl(CoopMem &m, bool want) {
+__device__ __forceinline__ void coop_dbl(CoopMem &m, bool want) {
     const uint32_t w = threadIdx.x >> 6, s = threadIdx.x & 63;
     CoopSlot c{&m, s, s, kCoopA};
     const bool live = want && !coop_is_identity(m, kCoopA, s);
@@ -500,16 +502,17 @@ __device__ __forceinline__ G1Xyzz28 block_sum_coop(uint32_t cnt, CoopMem &m, At 
     G1Xyzz28 acc = xyzz28_identity();
     for (uint32_t j = t; j < cnt; j += 256) acc = add_inline(acc, *at(j));
     if (w == 0) coop_store(m, kCoopA, s, acc);
-    for (uint32_t r = 1; r < 4; r++) {
-        if (cnt <= 64 * r) break;  // the later waves hold nothing
-        if (w == r) coop_store(m, kCoopB, s, acc);
+    // steps 0-2: the values of waves 1-3 join the 64 slots; steps 3-8: the slots are halved
+#pragma unroll 1
+    for (uint32_t step = 0; step < 9; step++) {
+        const bool join = step < 3;
+        const uint32_t off = join ? 0u : 32u >> (step - 3);
+        if (join ? cnt <= 64 * (step + 1) : cnt <= off) continue;  // nothing there (the same for every thread)
+        if (join && w == step + 1) coop_store(m, kCoopB, s, acc);
         __syncthreads();
-        coop_add(m, false, 0, 64);
+        coop_add(m, !join, off, join ? 64u : off);
     }
     __syncthreads();
-    for (uint32_t off = 32; off > 0; off >>= 1) {
-        if (cnt > off) coop_add(m, true, off, off);
-    }
     G1Xyzz28 r = coop_load(m, kCoopA, 0);
     __syncthreads();  // the caller may start the next sum
     return r;
@@ -528,15 +531,19 @@ __device__ __forceinline__ void block_sum_coop_pair(CoopMem &m, At0 at0, At1 at1
     // while the other waves take their turns
     auto fetch = [&](uint32_t r) { return s < 32 ? *at0((4 * r + w) * 32 + e) : *at1((4 * r + w) * 32 + e); };
     G1Xyzz28 mine = fetch(0);
-    for (uint32_t step = 0; step < 8; step++) {
-        if (w == (step & 3)) {
+    // steps 0-7: the eight loads (the first fills the A values, the others are added to them); steps 8-12: halvings
+#pragma unroll 1
+    for (uint32_t step = 0; step < 13; step++) {
+        const bool load = step < 8;
+        if (load && w == (step & 3)) {
             coop_store(m, step == 0 ? kCoopA : kCoopB, s, mine);
             if (step < 4) mine = fetch(1);
         }
         __syncthreads();
-        if (step > 0) coop_add(m, false, 0, 64);
+        if (step == 0) continue;
+        const uint32_t off = load ? 0u : 16u >> (step - 8);
+        coop_add(m, !load, off, load ? 64u : off, load ? 63u : 31u);
     }
-    for (uint32_t off = 16; off > 0; off >>= 1) coop_add(m, true, off, off, 31u);
 }
 
 // Buckets cut into more partials than a lane group handles go to the block path, in chunks of chunk_parts
@@ -825,18 +832,31 @@ __global__ __launch_bounds__(256) void k_finish(TailBatch tb, uint32_t sbits, ui
     };
     if (w == 0) coop_store(m, kCoopA, d, term(3 * d + 2));
     __syncthreads();
-    for (int k = 1; k >= 0; k--) {
-        coop_dbl(m, d < ndig);
-        if (w == 0) coop_store(m, kCoopB, d, term(3 * d + (uint32_t)k));
+    // The steps as one loop with one doubling and one addition in its body:
+    //   0, 2: double the digits;  1, 3: add term 3d + 1, then 3d;  4 .. 4 + 3 (ndig - 1) - 1: digit d doubled 3d times;
+    //   then T_all joins as slot ndig and four steps of a tree (offsets 8, 4, 2, 1) add the ndig + 1 slots
+    const uint32_t shifts = 3 * (ndig - 1), nsteps = 4 + shifts + 4;
+#pragma unroll 1
+    for (uint32_t i = 0; i < nsteps; i++) {
+        if (i < 4 + shifts && (i >= 4 || (i & 1) == 0)) {
+            coop_dbl(m, d < ndig && (i < 4 || i - 4 < 3 * d));
+            continue;
+        }
+        bool b_self = false, run = true;
+        uint32_t boff = 0, nact = ndig;
+        if (i < 4) {
+            if (w == 0) coop_store(m, kCoopB, d, term(3 * d + (i == 1 ? 1u : 0u)));
+        } else {
+            const uint32_t off = 8u >> (i - 4 - shifts);
+            if (off == 8 && w == 0 && d == ndig) coop_store(m, kCoopA, d, T[sbits]);
+            // slots s < off whose partner s + off is one of the ndig + 1 terms
+            b_self = true;
+            boff = off;
+            nact = ndig + 1 - off < off ? ndig + 1 - off : off;
+            run = ndig + 1 > off;
+        }
         __syncthreads();
-        coop_add(m, false, 0, ndig);
-    }
-    for (uint32_t step = 0; step < 3 * (ndig - 1); step++) coop_dbl(m, d < ndig && step < 3 * d);
-    if (w == 0 && d == ndig) coop_store(m, kCoopA, d, T[sbits]);
-    __syncthreads();
-    for (uint32_t off = 8; off > 0; off >>= 1) {
-        // slots s < off whose partner s + off is one of the ndig + 1 terms
-        if (ndig + 1 > off) coop_add(m, true, off, ndig + 1 - off < off ? ndig + 1 - off : off);
+        if (run) coop_add(m, b_self, boff, nact);
     }
     if (threadIdx.x == 0) *out = xyzz_to_jac(xyzz28_to(xyzz28_canon(coop_load(m, kCoopA, 0))));
 }
